@@ -1,0 +1,203 @@
+/*
+ * rtx_amd.h -- C-ABI of the MI355X ray-casting core.
+ *
+ * The core replaces, as one unit, what the reference does between
+ * `multiThreadedRayTracing(Scene&, Camera&, w, h, unsigned char* image)`
+ * (raytracer.cpp:93-141; single-thread twin raytracer.cpp:143-171) and the bytes
+ * it leaves in `image`: castRay (utils.cpp:134), intersect (utils.cpp:671),
+ * computePixelColor / computeShading (utils.cpp:1046 / 868), clamp + round
+ * (utils.cpp:125, raytracer.cpp:78-80).  Everything before that call -- JSON/PLY
+ * parsing, BVH build, transform and normal precompute -- stays on the host; its
+ * results cross this boundary as the plain-old-data `rtx_scene_desc` below.
+ *
+ * Every struct is plain C, pointers + counts only.  Field layouts mirror the
+ * reference's in-memory records so that a host that already holds a finished
+ * `scene::Scene` can point straight into it:
+ *   vertices        <- Scene::vertices.data()                 (scene.h:25-27,167)
+ *   rtx_bvh_node    <- MeshBVH::nodes.data()  (72-byte BVHNode, bvh.h:50-61)
+ *   face_indices    <- MeshBVH::faceIndices.data()            (bvh.h:66)
+ *   faces           <- Mesh::faces.data()     (VectorIntTriplet, scene.h:29-31,133)
+ *   vertex_normals  <- Scene::meshVertexNormals[i].data()     (scene.h:186)
+ *
+ * All functions return 0 on success and a negative RTX_E* code on failure;
+ * rtx_last_error() gives the message of the calling thread's last failure.
+ * There is no CPU fallback: without a usable HIP device every entry point
+ * that needs one fails with RTX_ENODEVICE.
+ */
+#ifndef RTX_AMD_H
+#define RTX_AMD_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RTX_ABI_VERSION 1
+
+enum {
+    RTX_OK = 0,
+    RTX_EINVAL = -1,     /* malformed description / argument            */
+    RTX_ENODEVICE = -2,  /* no HIP device, or device index out of range */
+    RTX_EHIP = -3,       /* a HIP runtime call failed                   */
+    RTX_ENOMEM = -4,     /* ray queues would exceed the configured cap  */
+    RTX_ELIMIT = -5      /* a structural limit was exceeded (BVH depth) */
+};
+
+/* Intersection::Kind, in the reference's enum order (scene.h:256). */
+enum { RTX_KIND_NONE = 0, RTX_KIND_PLANE = 1, RTX_KIND_SPHERE = 2, RTX_KIND_TRIANGLE = 3,
+       RTX_KIND_MESH = 4 };
+
+/* Material::type string (scene.h:110) as an enum; any other string shades like PLAIN. */
+enum { RTX_MAT_PLAIN = 0, RTX_MAT_MIRROR = 1, RTX_MAT_CONDUCTOR = 2, RTX_MAT_DIELECTRIC = 3,
+       RTX_MAT_OTHER = 4 };
+
+/* scene::Material (scene.h:102-114). */
+typedef struct rtx_material {
+    double ambient[3], diffuse[3], specular[3], mirror[3];
+    double phong_exponent, refraction_index, absorption_index;
+    double absorption_coefficient[3];
+    int32_t type;       /* RTX_MAT_*                                         */
+    int32_t is_mirror;  /* Material::isMirror (scene.cpp:446-460)            */
+} rtx_material;
+
+/* scene::PointLight after Scene::precomputeTransformations (scene.cpp:981-987). */
+typedef struct rtx_light { double position[3], intensity[3]; } rtx_light;
+
+/* scene::Camera after precomputeTransformations (scene.h:78-88, scene.cpp:971-979). */
+typedef struct rtx_camera {
+    double position[3], gaze[3], up[3];
+    double near_plane[4];   /* l, r, b, t */
+    double near_distance;
+    int32_t width, height;
+} rtx_camera;
+
+/* The three matrices of a transformed Object (scene.h:123-128), row-major, and its
+ * world-space AABB (Object::worldSpaceBounds, scene.cpp:867-879,947-957). */
+typedef struct rtx_xform {
+    double transform[16], inverse[16], normal[16];
+    double bounds_min[3], bounds_max[3];
+    int32_t has_bounds;       /* 0 for planes / spheres / free triangles              */
+    int32_t negative_scale;   /* Object::hasNegativeScale (informational)             */
+} rtx_xform;
+
+typedef struct rtx_plane    { double normal[3]; int32_t point, material, xform, pad; } rtx_plane;
+typedef struct rtx_sphere   { double radius;    int32_t center, material, xform, pad; } rtx_sphere;
+typedef struct rtx_triangle { int32_t v[3];     int32_t material, xform, pad; } rtx_triangle;
+
+/* scene::BVHNode (bvh.h:50-61): same 72-byte layout, so MeshBVH::nodes.data() can be
+ * passed as is.  left == -1 marks a leaf owning face_indices[first_face .. +face_count). */
+typedef struct rtx_bvh_node {
+    double bounds_min[3], bounds_max[3];
+    int32_t left, right, first_face, face_count, split_axis;
+    int32_t pad;
+} rtx_bvh_node;
+
+/* scene::Mesh (scene.h:131-134) + its MeshBVH (bvh.h:63-66) + its vertex normals. */
+typedef struct rtx_mesh {
+    const int32_t* faces;           /* n_faces x 3 indices into the global vertex pool  */
+    const rtx_bvh_node* nodes;      /* DFS pre-order as built by bvh.cpp:187-258        */
+    const int32_t* face_indices;    /* n_faces entries                                   */
+    const double* vertex_normals;   /* 3 doubles per *global* vertex id, or NULL         */
+    int32_t n_faces, n_nodes;
+    int32_t material;               /* index into materials, -1 = none (shades black)    */
+    int32_t smooth;                 /* Mesh::shadingMode == 's'                          */
+    int32_t xform;                  /* index into xforms, -1 = untransformed             */
+    int32_t pad;
+} rtx_mesh;
+
+/* scene::MeshInstance after precomputeTransformations (scene.h:150-155, scene.cpp:881-969).
+ * base_mesh < 0 marks an instance whose base could not be resolved (skipped, utils.cpp:758). */
+typedef struct rtx_instance { int32_t base_mesh, material, xform, pad; } rtx_instance;
+
+typedef struct rtx_scene_desc {
+    int32_t abi_version;                 /* RTX_ABI_VERSION */
+    int32_t max_recursion_depth;
+    int32_t enable_back_face_culling;    /* the -c flag (raytracer.cpp:199-207)          */
+    int32_t pad;
+    double background[3], ambient[3];
+    double shadow_ray_epsilon, intersection_test_epsilon;
+    const double* vertices;        int64_t n_vertices;   /* 3 doubles each */
+    const rtx_material* materials; int32_t n_materials;
+    const rtx_light* lights;       int32_t n_lights;
+    const rtx_xform* xforms;       int32_t n_xforms;
+    const rtx_plane* planes;       int32_t n_planes;
+    const rtx_sphere* spheres;     int32_t n_spheres;
+    const rtx_triangle* triangles; int32_t n_triangles;
+    const rtx_mesh* meshes;        int32_t n_meshes;
+    const rtx_instance* instances; int32_t n_instances;
+} rtx_scene_desc;
+
+/* Per-pixel record of the primary ray's closest hit, for parity checks.
+ * src: for MESH hits the object that produced the hit -- mesh index (meshes loop,
+ * utils.cpp:736-739) or n_meshes + instance index (instances loop, utils.cpp:756-790);
+ * for other kinds the container index.  distance is Intersection::distance. */
+typedef struct rtx_hit_id { int32_t kind, container, face, src; double distance; } rtx_hit_id;
+
+/* Work counters of one rtx_render call.  A "ray" is one closest-hit query the reference
+ * semantics require (one intersect() call, utils.cpp:671), excluding the calls whose result
+ * computePixelColor discards because depth > maxRecursionDepth (utils.cpp:1047). */
+typedef struct rtx_stats {
+    uint64_t rays, primary_rays, shadow_rays, secondary_rays;
+    uint64_t node_visits;      /* BLAS inner-node visits (two child boxes fetched each)    */
+    uint64_t tri_tests;        /* rayHitsTriangle evaluations                             */
+    uint64_t world_box_tests;  /* per-object world-AABB tests (utils.cpp:451,761)         */
+    uint64_t object_space_traversals;
+    uint64_t tlas_node_visits;
+    double kernel_ms;          /* HIP-event time of all kernels of the frame              */
+    double total_ms;           /* kernels + download of the image                         */
+    uint32_t generations, queue_overflows;
+} rtx_stats;
+
+typedef struct rtx_scene rtx_scene;   /* opaque: owns the device copy of the scene */
+
+/* Flatten `desc` into the device layout and upload it to HIP device `device`
+ * (replaces nothing in the reference; it is the "device SoA upload" the seam needs).
+ * The description may be freed after the call returns. */
+int rtx_scene_create(const rtx_scene_desc* desc, int device, rtx_scene** out);
+
+/* Replace the point lights (animated lights; same count not required). */
+int rtx_scene_update_lights(rtx_scene* scene, const rtx_light* lights, int32_t n_lights);
+
+/* Render one camera: the replacement for multiThreadedRayTracing (raytracer.cpp:93-141).
+ *  tile_w/tile_h/tile_first/tile_stride select an interleaved subset of tile_w x tile_h
+ *  pixel tiles (row-major tile numbering): tiles tile_first, tile_first+tile_stride, ...
+ *  Pass tile_stride = 1, tile_first = 0 (any tile size) for the whole frame.
+ *  rgb_out receives the selected tiles' pixels: for the whole frame this is the reference's
+ *  image layout (row-major, RGB interleaved, row 0 on top, raytracer.cpp:78-80); for a tile
+ *  subset the tiles are packed one after another, each tile_h rows of tile_w pixels
+ *  (edge tiles are clipped but still occupy a full tile_w*tile_h*3 slot).
+ *  rgb_is_device != 0: rgb_out is a device pointer on the scene's device.
+ *  hit_ids (host pointer or NULL): w*h records, whole-frame renders only.
+ *  stats may be NULL.  Blocking. */
+int rtx_render(rtx_scene* scene, const rtx_camera* camera,
+               int32_t tile_w, int32_t tile_h, int32_t tile_first, int32_t tile_stride,
+               uint8_t* rgb_out, int32_t rgb_is_device,
+               rtx_hit_id* hit_ids, rtx_stats* stats);
+
+/* Number of bytes rtx_render writes to rgb_out for the given tiling. */
+int64_t rtx_render_output_bytes(const rtx_camera* camera, int32_t tile_w, int32_t tile_h,
+                                int32_t tile_first, int32_t tile_stride);
+
+/* Scatter packed tiles (as written by rtx_render for each rank) back into a full
+ * row-major frame.  Host-side helper for the multi-GPU tile gather. */
+int rtx_unpack_tiles(const uint8_t* packed, int32_t width, int32_t height,
+                     int32_t tile_w, int32_t tile_h, int32_t tile_first, int32_t tile_stride,
+                     uint8_t* frame);
+
+/* Collect per-ray work counters in rtx_stats (slower kernels); default off. */
+int rtx_scene_set_counters(rtx_scene* scene, int32_t enable);
+
+/* Cap, in bytes, of the two ray queues together (default 32 GiB). */
+int rtx_scene_set_queue_limit(rtx_scene* scene, int64_t bytes);
+
+void rtx_scene_destroy(rtx_scene* scene);
+
+const char* rtx_last_error(void);
+int rtx_device_count(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RTX_AMD_H */

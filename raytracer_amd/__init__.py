@@ -1,0 +1,192 @@
+"""MI355X ray-casting core for the muratbayrktr/raytracer scene format.
+
+Python is only the thin host mirror used by tests, bench and the multi-GPU driver:
+``HostScene`` wraps the C++ scene pipeline (librtx_host.so: scene file -> finished
+description, the data the reference holds at raytracer.cpp:246) and ``DeviceScene`` wraps
+the HIP core (librtx_amd.so: the replacement for multiThreadedRayTracing,
+raytracer.cpp:93-141).  Both are plain C-ABI libraries loaded with ctypes; there is no
+CPU rendering path in this package -- ``DeviceScene`` raises when the HIP library or a
+GPU is missing.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _abi
+from ._abi import Camera, HitId, Light, SceneDesc, Stats, HIT_DTYPE  # noqa: F401
+
+__all__ = ["HostScene", "DeviceScene", "render_file", "RtxError"]
+
+
+class RtxError(RuntimeError):
+    pass
+
+
+_host_lib = None
+_amd_lib = None
+
+
+def host_lib():
+    global _host_lib
+    if _host_lib is None:
+        _host_lib = _abi.load_host_lib()
+    return _host_lib
+
+
+def amd_lib():
+    global _amd_lib
+    if _amd_lib is None:
+        try:
+            _amd_lib = _abi.load_amd_lib()
+        except OSError as e:  # fail loudly: no fallback renderer exists
+            raise RtxError(f"HIP core library not loadable ({e}); build it with `make product`") from e
+    return _amd_lib
+
+
+class HostScene:
+    """Scene file -> finished scene description (reference: raytracer.cpp:216-246)."""
+
+    def __init__(self, json_path: str, use_bvh: bool = True, enable_cull: bool = False):
+        self._lib = host_lib()
+        h = C.c_void_p()
+        rc = self._lib.rtx_host_load(os.fsencode(json_path), int(use_bvh), int(enable_cull), C.byref(h))
+        if rc != 0:
+            raise RtxError(self._lib.rtx_host_last_error().decode())
+        self._h = h
+        self.path = json_path
+
+    @property
+    def desc(self):
+        return self._lib.rtx_host_desc(self._h)
+
+    @property
+    def n_cameras(self) -> int:
+        return self._lib.rtx_host_camera_count(self._h)
+
+    def camera(self, index: int = 0):
+        cam = Camera()
+        name = C.create_string_buffer(512)
+        if self._lib.rtx_host_camera(self._h, index, C.byref(cam), name, 512) != 0:
+            raise RtxError(self._lib.rtx_host_last_error().decode())
+        return cam, name.value.decode()
+
+    def timings(self):
+        a, b = C.c_double(), C.c_double()
+        self._lib.rtx_host_timings(self._h, C.byref(a), C.byref(b))
+        return {"parse_ms": a.value, "preprocess_ms": b.value}
+
+    def dump(self, path: str):
+        if self._lib.rtx_host_dump(self._h, os.fsencode(path)) != 0:
+            raise RtxError(self._lib.rtx_host_last_error().decode())
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.rtx_host_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def write_ppm(path: str, rgb: np.ndarray):
+    rgb = np.ascontiguousarray(rgb, dtype=np.uint8)
+    h, w, _ = rgb.shape
+    if host_lib().rtx_host_write_ppm(os.fsencode(path), rgb.ctypes.data, w, h) != 0:
+        raise RtxError(host_lib().rtx_host_last_error().decode())
+
+
+def write_png(path: str, rgb: np.ndarray):
+    rgb = np.ascontiguousarray(rgb, dtype=np.uint8)
+    h, w, _ = rgb.shape
+    if host_lib().rtx_host_write_png(os.fsencode(path), rgb.ctypes.data, w, h) != 0:
+        raise RtxError(host_lib().rtx_host_last_error().decode())
+
+
+class DeviceScene:
+    """Device copy of a scene + render calls (reference: multiThreadedRayTracing)."""
+
+    def __init__(self, desc, device: int = 0):
+        self._lib = amd_lib()
+        h = C.c_void_p()
+        rc = self._lib.rtx_scene_create(desc, device, C.byref(h))
+        if rc != 0:
+            raise RtxError(f"rtx_scene_create failed ({rc}): {self._lib.rtx_last_error().decode()}")
+        self._h = h
+        self.device = device
+
+    def set_counters(self, enable: bool):
+        self._lib.rtx_scene_set_counters(self._h, int(enable))
+
+    def set_queue_limit(self, nbytes: int):
+        self._lib.rtx_scene_set_queue_limit(self._h, int(nbytes))
+
+    def update_lights(self, lights):
+        arr = (Light * len(lights))(*lights)
+        if self._lib.rtx_scene_update_lights(self._h, arr, len(lights)) != 0:
+            raise RtxError(self._lib.rtx_last_error().decode())
+
+    def render(self, cam: Camera, want_hits: bool = False):
+        """Whole frame -> (rgb[h][w][3] uint8, hit records or None, stats dict)."""
+        rgb = np.empty((cam.height, cam.width, 3), dtype=np.uint8)
+        hits = np.empty(cam.height * cam.width, dtype=HIT_DTYPE) if want_hits else None
+        st = Stats()
+        rc = self._lib.rtx_render(self._h, C.byref(cam), cam.width, cam.height, 0, 1,
+                                  rgb.ctypes.data, 0, hits.ctypes.data if want_hits else None,
+                                  C.byref(st))
+        if rc != 0:
+            raise RtxError(f"rtx_render failed ({rc}): {self._lib.rtx_last_error().decode()}")
+        return rgb, hits, st.as_dict()
+
+    def tile_bytes(self, cam, tile_w, tile_h, first, stride) -> int:
+        return int(self._lib.rtx_render_output_bytes(C.byref(cam), tile_w, tile_h, first, stride))
+
+    def render_tiles(self, cam: Camera, tile_w: int, tile_h: int, first: int, stride: int,
+                     out_ptr: int | None = None, out_is_device: bool = False):
+        """Interleaved tile subset -> packed uint8 buffer (or into ``out_ptr``)."""
+        n = self.tile_bytes(cam, tile_w, tile_h, first, stride)
+        st = Stats()
+        buf = None
+        if out_ptr is None:
+            buf = np.empty(n, dtype=np.uint8)
+            out_ptr, out_is_device = buf.ctypes.data, False
+        rc = self._lib.rtx_render(self._h, C.byref(cam), tile_w, tile_h, first, stride,
+                                  C.c_void_p(out_ptr), int(out_is_device), None, C.byref(st))
+        if rc != 0:
+            raise RtxError(f"rtx_render failed ({rc}): {self._lib.rtx_last_error().decode()}")
+        return buf, st.as_dict()
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.rtx_scene_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def unpack_tiles(packed: np.ndarray, width, height, tile_w, tile_h, first, stride, frame: np.ndarray):
+    packed = np.ascontiguousarray(packed, dtype=np.uint8)
+    rc = amd_lib().rtx_unpack_tiles(packed.ctypes.data, width, height, tile_w, tile_h, first, stride,
+                                    frame.ctypes.data)
+    if rc != 0:
+        raise RtxError(amd_lib().rtx_last_error().decode())
+
+
+def render_file(json_path: str, device: int = 0, camera: int = 0, enable_cull: bool = False):
+    """Convenience: load, upload, render one camera; returns (rgb, stats)."""
+    hs = HostScene(json_path, True, enable_cull)
+    ds = DeviceScene(hs.desc, device)
+    cam, _ = hs.camera(camera)
+    rgb, _, st = ds.render(cam)
+    ds.close()
+    hs.close()
+    return rgb, st
