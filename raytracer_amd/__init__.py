@@ -150,6 +150,8 @@ class DeviceScene:
                      out_ptr: int | None = None, out_is_device: bool = False):
         """Interleaved tile subset -> packed uint8 buffer (or into ``out_ptr``)."""
         n = self.tile_bytes(cam, tile_w, tile_h, first, stride)
+        if n < 0:
+            raise RtxError(f"bad tiling: {self._lib.rtx_last_error().decode()}")
         st = Stats()
         buf = None
         if out_ptr is None:

@@ -1,0 +1,638 @@
+// C-ABI of the ray-casting core (include/rtx_amd.h): scene flattening + upload, the
+// per-frame generation loop, download.  Host code only orchestrates; every pixel is
+// computed by the kernels in rtx_kernels.h.  There is no CPU rendering path here.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <climits>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <numeric>
+#include <string>
+#include <vector>
+
+#include "rtx_amd.h"
+#include "rtx_device_types.h"
+#include "rtx_kernels.h"
+
+using namespace rtxdev;
+
+namespace {
+
+thread_local std::string g_error;
+
+int fail(int code, const std::string& msg) { g_error = msg; return code; }
+
+#define HIP_TRY(expr)                                                                      \
+    do {                                                                                   \
+        hipError_t e_ = (expr);                                                            \
+        if (e_ != hipSuccess)                                                              \
+            return fail(RTX_EHIP, std::string(#expr) + ": " + hipGetErrorString(e_));      \
+    } while (0)
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    hipError_t ensure(size_t n) {
+        if (n <= bytes) return hipSuccess;
+        if (p) { (void)hipFree(p); p = nullptr; bytes = 0; }
+        hipError_t e = hipMalloc(&p, n);
+        if (e == hipSuccess) bytes = n;
+        return e;
+    }
+    template <typename T> hipError_t upload(const std::vector<T>& v) {
+        hipError_t e = ensure(std::max<size_t>(v.size() * sizeof(T), 16));
+        if (e != hipSuccess) return e;
+        if (!v.empty()) e = hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice);
+        return e;
+    }
+};
+
+struct HBox {
+    double mn[3], mx[3];
+    HBox() { for (int i = 0; i < 3; i++) { mn[i] = (double)1e30f; mx[i] = (double)-1e30f; } }   // bvh.h:13
+    void expand(const double* p) { for (int i = 0; i < 3; i++) { mn[i] = std::min(mn[i], p[i]); mx[i] = std::max(mx[i], p[i]); } }
+    void merge(const HBox& o) { for (int i = 0; i < 3; i++) { mn[i] = std::min(mn[i], o.mn[i]); mx[i] = std::max(mx[i], o.mx[i]); } }
+};
+
+}  // namespace
+
+struct rtx_scene {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    Scene dev{};                    // kernel argument (device pointers inside)
+    int n_meshes = 0;
+    bool counters_on = false;
+    int64_t queue_limit = (int64_t)32 << 30;
+    uint32_t queue_capacity = 0;    // rays per queue, grows on overflow and is then kept
+    DevBuf materials, lights, xforms, planes, spheres, ftris, meshes, insts, nodes, tris, tri_gn, tri_vn,
+        tri_face, tlas, tlas_order;
+    DevBuf accum, rgb, aov, ctrl, counters, queue[2];
+    ~rtx_scene() {
+        if (ev0) (void)hipEventDestroy(ev0);
+        if (ev1) (void)hipEventDestroy(ev1);
+        if (stream) (void)hipStreamDestroy(stream);
+    }
+};
+
+namespace {
+
+// ---- BLAS flattening ---------------------------------------------------------------------
+struct Flat {
+    std::vector<Node> nodes;
+    std::vector<Tri> tris;
+    std::vector<double> tri_gn, tri_vn;
+    std::vector<int32_t> tri_face;
+    std::vector<Mesh> meshes;
+    bool any_vn = false;
+};
+
+int push_tri(const rtx_scene_desc& d, const rtx_mesh& m, int face, Flat& F) {
+    if (face < 0 || face >= m.n_faces) return fail(RTX_EINVAL, "face index outside the mesh");
+    const int32_t* f = m.faces + 3 * (size_t)face;
+    for (int k = 0; k < 3; k++)
+        if (f[k] < 0 || f[k] >= d.n_vertices) return fail(RTX_EINVAL, "face references a vertex outside the pool");
+    const double* a = d.vertices + 3 * (size_t)f[0];
+    const double* b = d.vertices + 3 * (size_t)f[1];
+    const double* c = d.vertices + 3 * (size_t)f[2];
+    Tri t;
+    for (int k = 0; k < 3; k++) { t.a[k] = a[k]; t.e1[k] = b[k] - a[k]; t.e2[k] = c[k] - a[k]; }
+    F.tris.push_back(t);
+    // geometricNormal = normalize(crossProduct(e1, e2)), utils.cpp:319-321
+    double nx = t.e1[1] * t.e2[2] - t.e1[2] * t.e2[1];
+    double ny = t.e1[2] * t.e2[0] - t.e1[0] * t.e2[2];
+    double nz = t.e1[0] * t.e2[1] - t.e1[1] * t.e2[0];
+    double len = std::sqrt(nx * nx + ny * ny + nz * nz);
+    F.tri_gn.push_back(nx / len); F.tri_gn.push_back(ny / len); F.tri_gn.push_back(nz / len);
+    F.tri_face.push_back(face);
+    if (m.smooth && m.vertex_normals)
+        for (int k = 0; k < 3; k++)
+            for (int q = 0; q < 3; q++) F.tri_vn.push_back(m.vertex_normals[3 * (size_t)f[k] + q]);
+    else
+        for (int q = 0; q < 9; q++) F.tri_vn.push_back(0.0);
+    return RTX_OK;
+}
+
+int flatten_mesh(const rtx_scene_desc& d, const rtx_mesh& m, Flat& F) {
+    Mesh out{};
+    out.material = m.material; out.smooth = m.smooth; out.xform = m.xform; out.n_faces = m.n_faces;
+    out.has_vn = (m.smooth && m.vertex_normals) ? 1 : 0;
+    if (out.has_vn) F.any_vn = true;
+    if (m.n_faces < 0 || (m.n_faces > 0 && !m.faces)) return fail(RTX_EINVAL, "mesh without faces pointer");
+    if (m.n_faces == 0) { F.meshes.push_back(out); return RTX_OK; }
+    if (m.n_nodes <= 0 || !m.nodes) {
+        // No BVH supplied (the -b 0 mode): one leaf holding every face in face order, which is
+        // the order of the reference's brute-force loop (utils.cpp:434-441).
+        HBox box;
+        out.root_ref = (int32_t)F.tris.size();
+        out.root_count = m.n_faces;
+        for (int f = 0; f < m.n_faces; f++) {
+            int rc = push_tri(d, m, f, F);
+            if (rc) return rc;
+            for (int k = 0; k < 3; k++) box.expand(d.vertices + 3 * (size_t)m.faces[3 * (size_t)f + k]);
+        }
+        memcpy(out.rmin, box.mn, sizeof box.mn); memcpy(out.rmax, box.mx, sizeof box.mx);
+        F.meshes.push_back(out);
+        return RTX_OK;
+    }
+    if (!m.face_indices) return fail(RTX_EINVAL, "mesh BVH without face_indices");
+    const int n = m.n_nodes;
+    // device ids for inner nodes, triangle ranges for leaves (in node order = DFS pre-order)
+    std::vector<int32_t> inner_id((size_t)n, -1), leaf_start((size_t)n, -1);
+    int32_t next_inner = (int32_t)F.nodes.size();
+    for (int i = 0; i < n; i++) {
+        const rtx_bvh_node& nd = m.nodes[i];
+        if (nd.left == -1) {
+            if (nd.face_count <= 0 || nd.first_face < 0 || (int64_t)nd.first_face + nd.face_count > m.n_faces)
+                return fail(RTX_EINVAL, "BVH leaf range outside face_indices");
+            leaf_start[(size_t)i] = (int32_t)F.tris.size();
+            for (int k = 0; k < nd.face_count; k++) {
+                int rc = push_tri(d, m, m.face_indices[nd.first_face + k], F);
+                if (rc) return rc;
+            }
+        } else {
+            if (nd.left < 0 || nd.left >= n || nd.right < 0 || nd.right >= n || nd.split_axis < 0 || nd.split_axis > 2)
+                return fail(RTX_EINVAL, "BVH inner node with invalid children");
+            inner_id[(size_t)i] = next_inner++;
+        }
+    }
+    F.nodes.resize((size_t)next_inner);
+    auto child = [&](int c, int32_t& ref, int32_t& cnt) {
+        if (m.nodes[c].left == -1) { ref = leaf_start[(size_t)c]; cnt = m.nodes[c].face_count; }
+        else { ref = inner_id[(size_t)c]; cnt = 0; }
+    };
+    for (int i = 0; i < n; i++) {
+        if (inner_id[(size_t)i] < 0) continue;
+        const rtx_bvh_node& nd = m.nodes[i];
+        Node& o = F.nodes[(size_t)inner_id[(size_t)i]];
+        memset(&o, 0, sizeof o);
+        memcpy(o.lmin, m.nodes[nd.left].bounds_min, 24); memcpy(o.lmax, m.nodes[nd.left].bounds_max, 24);
+        memcpy(o.rmin, m.nodes[nd.right].bounds_min, 24); memcpy(o.rmax, m.nodes[nd.right].bounds_max, 24);
+        child(nd.left, o.lref, o.lcount);
+        child(nd.right, o.rref, o.rcount);
+        o.axis = nd.split_axis;
+    }
+    // depth check: the traversal stack holds one entry per level
+    {
+        std::vector<std::pair<int, int>> st;
+        st.emplace_back(0, 1);
+        int max_depth = 0;
+        size_t visited = 0;
+        while (!st.empty()) {
+            auto [i, dep] = st.back(); st.pop_back();
+            if (++visited > (size_t)n) return fail(RTX_EINVAL, "BVH is not a tree");
+            max_depth = std::max(max_depth, dep);
+            if (m.nodes[i].left != -1) { st.emplace_back(m.nodes[i].left, dep + 1); st.emplace_back(m.nodes[i].right, dep + 1); }
+        }
+        if (max_depth > RTX_STACK - 2) return fail(RTX_ELIMIT, "BVH deeper than the traversal stack");
+    }
+    memcpy(out.rmin, m.nodes[0].bounds_min, 24); memcpy(out.rmax, m.nodes[0].bounds_max, 24);
+    child(0, out.root_ref, out.root_count);
+    F.meshes.push_back(out);
+    return RTX_OK;
+}
+
+// ---- TLAS ---------------------------------------------------------------------------------
+struct TlasItem { HBox box; int idx; double c[3]; };
+
+struct TlasBuild {
+    std::vector<TlasItem>& items;
+    std::vector<TlasNode>& nodes;
+    std::vector<int32_t>& order;
+    struct Sub { int32_t ref, cnt, min_idx, max_idx; HBox box; };
+
+    Sub build(int lo, int hi) {
+        Sub s;
+        s.min_idx = INT_MAX; s.max_idx = -1;
+        for (int i = lo; i < hi; i++) {
+            s.box.merge(items[(size_t)i].box);
+            s.min_idx = std::min(s.min_idx, items[(size_t)i].idx);
+            s.max_idx = std::max(s.max_idx, items[(size_t)i].idx);
+        }
+        if (hi - lo <= 2) {
+            std::sort(items.begin() + lo, items.begin() + hi, [](const TlasItem& a, const TlasItem& b) { return a.idx < b.idx; });
+            s.ref = (int32_t)order.size(); s.cnt = hi - lo;
+            for (int i = lo; i < hi; i++) order.push_back(items[(size_t)i].idx);
+            return s;
+        }
+        double cmn[3] = {1e300, 1e300, 1e300}, cmx[3] = {-1e300, -1e300, -1e300};
+        for (int i = lo; i < hi; i++)
+            for (int k = 0; k < 3; k++) { cmn[k] = std::min(cmn[k], items[(size_t)i].c[k]); cmx[k] = std::max(cmx[k], items[(size_t)i].c[k]); }
+        int axis = 0;
+        for (int k = 1; k < 3; k++) if (cmx[k] - cmn[k] > cmx[axis] - cmn[axis]) axis = k;
+        int mid = lo + (hi - lo) / 2;
+        std::nth_element(items.begin() + lo, items.begin() + mid, items.begin() + hi,
+                         [axis](const TlasItem& a, const TlasItem& b) { return a.c[axis] < b.c[axis]; });
+        int32_t self = (int32_t)nodes.size();
+        nodes.emplace_back();
+        Sub l = build(lo, mid), r = build(mid, hi);
+        TlasNode& n = nodes[(size_t)self];
+        memcpy(n.lmin, l.box.mn, 24); memcpy(n.lmax, l.box.mx, 24);
+        memcpy(n.rmin, r.box.mn, 24); memcpy(n.rmax, r.box.mx, 24);
+        n.lref = l.ref; n.lcount = l.cnt; n.rref = r.ref; n.rcount = r.cnt;
+        n.lmin_idx = l.min_idx; n.lmax_idx = l.max_idx; n.rmin_idx = r.min_idx; n.rmax_idx = r.max_idx;
+        s.ref = self; s.cnt = 0;
+        return s;
+    }
+};
+
+int check_index(int v, int n, bool allow_neg, const char* what) {
+    if ((v < 0 && !(allow_neg && v == -1)) || v >= n) return fail(RTX_EINVAL, std::string("index out of range: ") + what);
+    return RTX_OK;
+}
+
+int build_scene(rtx_scene& sc, const rtx_scene_desc& d) {
+    if (d.abi_version != RTX_ABI_VERSION) return fail(RTX_EINVAL, "rtx_scene_desc.abi_version mismatch");
+    if (d.max_recursion_depth < 0 || d.max_recursion_depth > 250) return fail(RTX_ELIMIT, "max_recursion_depth outside 0..250");
+    if (d.n_vertices < 0 || (d.n_vertices > 0 && !d.vertices)) return fail(RTX_EINVAL, "vertices");
+    auto need = [](const void* p, int n) { return n < 0 || (n > 0 && !p); };
+    if (need(d.materials, d.n_materials) || need(d.lights, d.n_lights) || need(d.xforms, d.n_xforms) ||
+        need(d.planes, d.n_planes) || need(d.spheres, d.n_spheres) || need(d.triangles, d.n_triangles) ||
+        need(d.meshes, d.n_meshes) || need(d.instances, d.n_instances))
+        return fail(RTX_EINVAL, "null array with non-zero count");
+
+    Scene& S = sc.dev;
+    memset(&S, 0, sizeof S);
+    memcpy(S.bg, d.background, 24); memcpy(S.ambient, d.ambient, 24);
+    S.shadow_eps = d.shadow_ray_epsilon; S.isect_eps = d.intersection_test_epsilon;
+    S.max_depth = d.max_recursion_depth; S.cull = d.enable_back_face_culling ? 1 : 0;
+    S.n_lights = d.n_lights; S.n_planes = d.n_planes; S.n_spheres = d.n_spheres; S.n_ftris = d.n_triangles;
+    S.n_meshes = d.n_meshes; S.n_insts = 0;
+    sc.n_meshes = d.n_meshes;
+
+    std::vector<Material> mats((size_t)d.n_materials);
+    for (int i = 0; i < d.n_materials; i++) {
+        const rtx_material& m = d.materials[i];
+        Material& o = mats[(size_t)i];
+        memcpy(o.ambient, m.ambient, 24); memcpy(o.diffuse, m.diffuse, 24); memcpy(o.specular, m.specular, 24);
+        memcpy(o.mirror, m.mirror, 24); memcpy(o.sigma, m.absorption_coefficient, 24);
+        o.phong = m.phong_exponent; o.n = m.refraction_index; o.k = m.absorption_index;
+        o.type = m.type; o.is_mirror = m.is_mirror;
+    }
+    std::vector<Light> lights((size_t)d.n_lights);
+    for (int i = 0; i < d.n_lights; i++) { memcpy(lights[(size_t)i].p, d.lights[i].position, 24); memcpy(lights[(size_t)i].i, d.lights[i].intensity, 24); }
+    std::vector<Xform> xfs((size_t)d.n_xforms);
+    for (int i = 0; i < d.n_xforms; i++) {
+        const rtx_xform& x = d.xforms[i];
+        Xform& o = xfs[(size_t)i];
+        memcpy(o.m, x.transform, 128); memcpy(o.inv, x.inverse, 128); memcpy(o.nrm, x.normal, 128);
+        memcpy(o.bmin, x.bounds_min, 24); memcpy(o.bmax, x.bounds_max, 24);
+        o.has_bounds = x.has_bounds; o.pad = 0;
+    }
+    int rc;
+    std::vector<Plane> planes((size_t)d.n_planes);
+    for (int i = 0; i < d.n_planes; i++) {
+        const rtx_plane& p = d.planes[i];
+        if ((rc = check_index(p.point, (int)d.n_vertices, false, "plane point"))) return rc;
+        if ((rc = check_index(p.material, d.n_materials, true, "plane material"))) return rc;
+        if ((rc = check_index(p.xform, d.n_xforms, true, "plane xform"))) return rc;
+        memcpy(planes[(size_t)i].n, p.normal, 24); memcpy(planes[(size_t)i].a, d.vertices + 3 * (size_t)p.point, 24);
+        planes[(size_t)i].material = p.material; planes[(size_t)i].xform = p.xform;
+    }
+    std::vector<Sphere> spheres((size_t)d.n_spheres);
+    for (int i = 0; i < d.n_spheres; i++) {
+        const rtx_sphere& p = d.spheres[i];
+        if ((rc = check_index(p.center, (int)d.n_vertices, false, "sphere center"))) return rc;
+        if ((rc = check_index(p.material, d.n_materials, true, "sphere material"))) return rc;
+        if ((rc = check_index(p.xform, d.n_xforms, true, "sphere xform"))) return rc;
+        memcpy(spheres[(size_t)i].c, d.vertices + 3 * (size_t)p.center, 24);
+        spheres[(size_t)i].r = p.radius; spheres[(size_t)i].material = p.material; spheres[(size_t)i].xform = p.xform;
+    }
+    std::vector<FreeTri> ftris((size_t)d.n_triangles);
+    for (int i = 0; i < d.n_triangles; i++) {
+        const rtx_triangle& p = d.triangles[i];
+        for (int k = 0; k < 3; k++) if ((rc = check_index(p.v[k], (int)d.n_vertices, false, "triangle vertex"))) return rc;
+        if ((rc = check_index(p.material, d.n_materials, true, "triangle material"))) return rc;
+        if ((rc = check_index(p.xform, d.n_xforms, true, "triangle xform"))) return rc;
+        const double* a = d.vertices + 3 * (size_t)p.v[0];
+        const double* b = d.vertices + 3 * (size_t)p.v[1];
+        const double* c = d.vertices + 3 * (size_t)p.v[2];
+        FreeTri& o = ftris[(size_t)i];
+        for (int k = 0; k < 3; k++) { o.a[k] = a[k]; o.e1[k] = b[k] - a[k]; o.e2[k] = c[k] - a[k]; }
+        double nx = o.e1[1] * o.e2[2] - o.e1[2] * o.e2[1];
+        double ny = o.e1[2] * o.e2[0] - o.e1[0] * o.e2[2];
+        double nz = o.e1[0] * o.e2[1] - o.e1[1] * o.e2[0];
+        double len = std::sqrt(nx * nx + ny * ny + nz * nz);
+        o.gn[0] = nx / len; o.gn[1] = ny / len; o.gn[2] = nz / len;
+        o.material = p.material; o.xform = p.xform;
+    }
+    Flat F;
+    for (int i = 0; i < d.n_meshes; i++) {
+        const rtx_mesh& m = d.meshes[i];
+        if ((rc = check_index(m.material, d.n_materials, true, "mesh material"))) return rc;
+        if ((rc = check_index(m.xform, d.n_xforms, true, "mesh xform"))) return rc;
+        if ((rc = flatten_mesh(d, m, F))) return rc;
+    }
+    if (F.tris.size() > (size_t)INT_MAX / 2) return fail(RTX_ELIMIT, "too many triangles");
+
+    // instances: effective transform (utils.cpp:418,446,476) and TLAS over their world boxes
+    std::vector<Inst> insts((size_t)d.n_instances);
+    std::vector<TlasItem> items;
+    for (int i = 0; i < d.n_instances; i++) {
+        const rtx_instance& in = d.instances[i];
+        Inst& o = insts[(size_t)i];
+        o.base_mesh = in.base_mesh; o.material = in.material; o.xform = -1; o.pad = 0;
+        if (in.base_mesh < 0) continue;
+        if ((rc = check_index(in.base_mesh, d.n_meshes, false, "instance base mesh"))) return rc;
+        if ((rc = check_index(in.material, d.n_materials, true, "instance material"))) return rc;
+        if ((rc = check_index(in.xform, d.n_xforms, true, "instance xform"))) return rc;
+        const Mesh& bm = F.meshes[(size_t)in.base_mesh];
+        o.xform = in.xform >= 0 ? in.xform : bm.xform;
+        if (bm.n_faces <= 0) continue;      // cannot produce a hit or touch the record
+        TlasItem it;
+        it.idx = i;
+        if (o.xform >= 0 && xfs[(size_t)o.xform].has_bounds) {
+            memcpy(it.box.mn, xfs[(size_t)o.xform].bmin, 24); memcpy(it.box.mx, xfs[(size_t)o.xform].bmax, 24);
+        } else if (o.xform < 0) {
+            memcpy(it.box.mn, bm.rmin, 24); memcpy(it.box.mx, bm.rmax, 24);
+        } else {
+            for (int k = 0; k < 3; k++) { it.box.mn[k] = -1e300; it.box.mx[k] = 1e300; }
+        }
+        for (int k = 0; k < 3; k++) it.c[k] = 0.5 * it.box.mn[k] + 0.5 * it.box.mx[k];
+        items.push_back(it);
+    }
+    std::vector<TlasNode> tlas;
+    std::vector<int32_t> order;
+    if (!items.empty()) {
+        TlasBuild tb{items, tlas, order};
+        TlasBuild::Sub root = tb.build(0, (int)items.size());
+        memcpy(S.tl_min, root.box.mn, 24); memcpy(S.tl_max, root.box.mx, 24);
+        S.tl_ref = root.ref; S.tl_count = root.cnt; S.tl_min_idx = root.min_idx; S.tl_max_idx = root.max_idx;
+        S.n_insts = d.n_instances;
+    }
+
+    HIP_TRY(sc.materials.upload(mats));   S.materials = (const Material*)sc.materials.p;
+    HIP_TRY(sc.lights.upload(lights));    S.lights = (const Light*)sc.lights.p;
+    HIP_TRY(sc.xforms.upload(xfs));       S.xforms = (const Xform*)sc.xforms.p;
+    HIP_TRY(sc.planes.upload(planes));    S.planes = (const Plane*)sc.planes.p;
+    HIP_TRY(sc.spheres.upload(spheres));  S.spheres = (const Sphere*)sc.spheres.p;
+    HIP_TRY(sc.ftris.upload(ftris));      S.ftris = (const FreeTri*)sc.ftris.p;
+    HIP_TRY(sc.meshes.upload(F.meshes));  S.meshes = (const Mesh*)sc.meshes.p;
+    HIP_TRY(sc.insts.upload(insts));      S.insts = (const Inst*)sc.insts.p;
+    HIP_TRY(sc.nodes.upload(F.nodes));    S.nodes = (const Node*)sc.nodes.p;
+    HIP_TRY(sc.tris.upload(F.tris));      S.tris = (const Tri*)sc.tris.p;
+    HIP_TRY(sc.tri_gn.upload(F.tri_gn));  S.tri_gn = (const double*)sc.tri_gn.p;
+    if (F.any_vn) { HIP_TRY(sc.tri_vn.upload(F.tri_vn)); S.tri_vn = (const double*)sc.tri_vn.p; }
+    else {
+        // no smooth mesh: keep has_vn = 0 everywhere, nothing to upload
+        S.tri_vn = nullptr;
+    }
+    HIP_TRY(sc.tri_face.upload(F.tri_face)); S.tri_face = (const int32_t*)sc.tri_face.p;
+    HIP_TRY(sc.tlas.upload(tlas));        S.tlas = (const TlasNode*)sc.tlas.p;
+    HIP_TRY(sc.tlas_order.upload(order)); S.tlas_order = (const int32_t*)sc.tlas_order.p;
+    return RTX_OK;
+}
+
+struct TileGeom { int tiles_x, tiles_y, n_tiles, n_sel; int64_t out_bytes; };
+
+int tile_geometry(const rtx_camera* cam, int tw, int th, int first, int stride, TileGeom& g) {
+    if (!cam || cam->width <= 0 || cam->height <= 0) return fail(RTX_EINVAL, "camera resolution");
+    if (tw <= 0 || th <= 0 || stride <= 0 || first < 0) return fail(RTX_EINVAL, "tile parameters");
+    g.tiles_x = (cam->width + tw - 1) / tw; g.tiles_y = (cam->height + th - 1) / th;
+    g.n_tiles = g.tiles_x * g.tiles_y;
+    g.n_sel = first >= g.n_tiles ? 0 : (g.n_tiles - first + stride - 1) / stride;
+    g.out_bytes = (int64_t)g.n_sel * tw * th * 3;
+    return RTX_OK;
+}
+
+Queue make_queue(void* base, uint32_t cap) {
+    Queue q;
+    char* p = (char*)base;
+    auto take = [&](size_t elem) { void* r = p; p += (size_t)cap * elem; return r; };
+    q.ox = (double*)take(8); q.oy = (double*)take(8); q.oz = (double*)take(8);
+    q.dx = (double*)take(8); q.dy = (double*)take(8); q.dz = (double*)take(8);
+    q.wx = (double*)take(8); q.wy = (double*)take(8); q.wz = (double*)take(8);
+    q.aux = (double*)take(8);
+    q.pixel = (uint32_t*)take(4); q.meta = (uint32_t*)take(4);
+    q.capacity = cap;
+    return q;
+}
+constexpr size_t kRayBytes = 10 * 8 + 2 * 4;
+
+}  // namespace
+
+extern "C" {
+
+const char* rtx_last_error(void) { return g_error.c_str(); }
+
+int rtx_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int rtx_scene_create(const rtx_scene_desc* desc, int device, rtx_scene** out) {
+    if (!desc || !out) return fail(RTX_EINVAL, "null argument");
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return fail(RTX_ENODEVICE, "no HIP device available");
+    if (device < 0 || device >= n) return fail(RTX_ENODEVICE, "device index out of range");
+    HIP_TRY(hipSetDevice(device));
+    rtx_scene* sc = new rtx_scene();
+    sc->device = device;
+    int rc = build_scene(*sc, *desc);
+    if (rc == RTX_OK) {
+        hipError_t e = hipStreamCreateWithFlags(&sc->stream, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipEventCreate(&sc->ev0);
+        if (e == hipSuccess) e = hipEventCreate(&sc->ev1);
+        if (e != hipSuccess) rc = fail(RTX_EHIP, hipGetErrorString(e));
+    }
+    if (rc != RTX_OK) { delete sc; return rc; }
+    *out = sc;
+    return RTX_OK;
+}
+
+int rtx_scene_update_lights(rtx_scene* sc, const rtx_light* lights, int32_t n_lights) {
+    if (!sc || n_lights < 0 || (n_lights > 0 && !lights)) return fail(RTX_EINVAL, "bad argument");
+    HIP_TRY(hipSetDevice(sc->device));
+    std::vector<Light> l((size_t)n_lights);
+    for (int i = 0; i < n_lights; i++) { memcpy(l[(size_t)i].p, lights[i].position, 24); memcpy(l[(size_t)i].i, lights[i].intensity, 24); }
+    HIP_TRY(hipStreamSynchronize(sc->stream));
+    HIP_TRY(sc->lights.upload(l));
+    sc->dev.lights = (const Light*)sc->lights.p;
+    sc->dev.n_lights = n_lights;
+    return RTX_OK;
+}
+
+int rtx_scene_set_counters(rtx_scene* sc, int32_t enable) {
+    if (!sc) return fail(RTX_EINVAL, "null scene");
+    sc->counters_on = enable != 0;
+    return RTX_OK;
+}
+
+int rtx_scene_set_queue_limit(rtx_scene* sc, int64_t bytes) {
+    if (!sc || bytes < (int64_t)(1 << 20)) return fail(RTX_EINVAL, "bad queue limit");
+    sc->queue_limit = bytes;
+    return RTX_OK;
+}
+
+void rtx_scene_destroy(rtx_scene* sc) {
+    if (!sc) return;
+    (void)hipSetDevice(sc->device);
+    if (sc->stream) (void)hipStreamSynchronize(sc->stream);
+    delete sc;
+}
+
+int64_t rtx_render_output_bytes(const rtx_camera* cam, int32_t tw, int32_t th, int32_t first, int32_t stride) {
+    TileGeom g;
+    if (tile_geometry(cam, tw, th, first, stride, g)) return -1;
+    return g.out_bytes;
+}
+
+int rtx_unpack_tiles(const uint8_t* packed, int32_t width, int32_t height, int32_t tw, int32_t th,
+                     int32_t first, int32_t stride, uint8_t* frame) {
+    if (!packed || !frame) return fail(RTX_EINVAL, "null argument");
+    rtx_camera cam{};
+    cam.width = width; cam.height = height;
+    TileGeom g;
+    int rc = tile_geometry(&cam, tw, th, first, stride, g);
+    if (rc) return rc;
+    for (int k = 0; k < g.n_sel; k++) {
+        int tile = first + k * stride;
+        int x0 = (tile % g.tiles_x) * tw, y0 = (tile / g.tiles_x) * th;
+        const uint8_t* src = packed + (size_t)k * tw * th * 3;
+        for (int y = 0; y < th && y0 + y < height; y++) {
+            int w = std::min(tw, width - x0);
+            memcpy(frame + ((size_t)(y0 + y) * width + x0) * 3, src + (size_t)y * tw * 3, (size_t)w * 3);
+        }
+    }
+    return RTX_OK;
+}
+
+int rtx_render(rtx_scene* sc, const rtx_camera* cam, int32_t tw, int32_t th, int32_t first, int32_t stride,
+               uint8_t* rgb_out, int32_t rgb_is_device, rtx_hit_id* hit_ids, rtx_stats* stats) {
+    if (!sc || !cam || !rgb_out) return fail(RTX_EINVAL, "null argument");
+    TileGeom g;
+    int rc = tile_geometry(cam, tw, th, first, stride, g);
+    if (rc) return rc;
+    const bool whole = (g.n_tiles == 1 && first == 0);
+    if (hit_ids && !whole) return fail(RTX_EINVAL, "hit_ids are only available for whole-frame renders");
+    if (stats) memset(stats, 0, sizeof *stats);
+    if (g.n_sel == 0) return RTX_OK;
+    HIP_TRY(hipSetDevice(sc->device));
+    auto wall0 = std::chrono::high_resolution_clock::now();
+
+    // camera basis: utils.cpp:135-146, evaluated once per frame instead of once per pixel
+    Frame F{};
+    {
+        auto norm = [](const double* a, double* o) {
+            double len = std::sqrt(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]);
+            o[0] = a[0] / len; o[1] = a[1] / len; o[2] = a[2] / len;
+        };
+        double w[3], v[3], u[3], m[3];
+        norm(cam->gaze, w);
+        for (double& x : w) x = -x;
+        norm(cam->up, v);
+        u[0] = v[1] * w[2] - v[2] * w[1]; u[1] = v[2] * w[0] - v[0] * w[2]; u[2] = v[0] * w[1] - v[1] * w[0];
+        const double l = cam->near_plane[0], r = cam->near_plane[1], b = cam->near_plane[2], t = cam->near_plane[3];
+        for (int k = 0; k < 3; k++) {
+            m[k] = cam->position[k] - w[k] * cam->near_distance;
+            F.q[k] = (m[k] + l * u[k]) + t * v[k];
+            F.e[k] = cam->position[k]; F.u[k] = u[k]; F.v[k] = v[k];
+        }
+        F.r_minus_l = r - l; F.t_minus_b = t - b;
+        F.width = cam->width; F.height = cam->height;
+        F.tile_w = tw; F.tile_h = th; F.tiles_x = g.tiles_x; F.tile_first = first; F.tile_stride = stride;
+    }
+    const int64_t blocks_per_tile = (int64_t)((tw + 7) / 8) * ((th + 7) / 8);
+    const int64_t n_items0 = (int64_t)g.n_sel * blocks_per_tile * 64;
+    const int64_t n_local_px = (int64_t)g.n_sel * tw * th;
+    if (n_items0 > (int64_t)0x7FFFFFF0 || n_local_px * 3 > (int64_t)0x7FFFFFF0) return fail(RTX_ELIMIT, "frame too large for one call");
+    F.n_local_pixels = (int32_t)n_items0;
+
+    const int G = sc->dev.max_depth + 2;
+    HIP_TRY(sc->accum.ensure((size_t)n_local_px * 3 * sizeof(double)));
+    HIP_TRY(sc->rgb.ensure((size_t)n_local_px * 3));
+    HIP_TRY(sc->ctrl.ensure((size_t)(G + 1) * sizeof(GenCtrl)));
+    HIP_TRY(sc->counters.ensure(sizeof(Counters)));
+    if (hit_ids) HIP_TRY(sc->aov.ensure((size_t)cam->width * cam->height * sizeof(rtx_hit_id)));
+
+    int dev_cus = 256;
+    {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, sc->device) == hipSuccess && prop.multiProcessorCount > 0) dev_cus = prop.multiProcessorCount;
+    }
+    const unsigned persistent_blocks = (unsigned)dev_cus * 8u;
+
+    if (sc->queue_capacity == 0) {
+        int64_t want = std::max<int64_t>(n_local_px * (int64_t)(sc->dev.n_lights + 2), 1 << 16);
+        sc->queue_capacity = (uint32_t)std::min<int64_t>(want, 0x7FFFFFF0);
+    }
+    uint32_t overflows = 0;
+    float kernel_ms = 0.f;
+    while (true) {
+        if ((int64_t)sc->queue_capacity * (int64_t)kRayBytes * 2 > sc->queue_limit) {
+            uint32_t cap = (uint32_t)(sc->queue_limit / (2 * (int64_t)kRayBytes));
+            if (overflows > 0 && cap <= sc->queue_capacity / 2 + 1)
+                return fail(RTX_ENOMEM, "ray queues exceed the configured limit; render fewer tiles per call or raise the limit");
+            sc->queue_capacity = cap;
+        }
+        HIP_TRY(sc->queue[0].ensure((size_t)sc->queue_capacity * kRayBytes));
+        HIP_TRY(sc->queue[1].ensure((size_t)sc->queue_capacity * kRayBytes));
+        Queue q[2] = {make_queue(sc->queue[0].p, sc->queue_capacity), make_queue(sc->queue[1].p, sc->queue_capacity)};
+
+        HIP_TRY(hipMemsetAsync(sc->ctrl.p, 0, (size_t)(G + 1) * sizeof(GenCtrl), sc->stream));
+        HIP_TRY(hipMemsetAsync(sc->accum.p, 0, (size_t)n_local_px * 3 * sizeof(double), sc->stream));
+        if (sc->counters_on) HIP_TRY(hipMemsetAsync(sc->counters.p, 0, sizeof(Counters), sc->stream));
+        HIP_TRY(hipEventRecord(sc->ev0, sc->stream));
+        for (int gen = 0; gen < G; gen++) {
+            unsigned blocks = persistent_blocks;
+            if (gen == 0) blocks = (unsigned)std::min<int64_t>(persistent_blocks, (n_items0 + 255) / 256);
+            const Queue& qin = q[(gen + 1) & 1];
+            const Queue& qout = q[gen & 1];
+            rtx_hit_id* aov = (gen == 0 && hit_ids) ? (rtx_hit_id*)sc->aov.p : nullptr;
+            if (sc->counters_on)
+                hipLaunchKernelGGL(k_trace<true>, dim3(blocks), dim3(256), 0, sc->stream, sc->dev, F, qin, qout,
+                                   (GenCtrl*)sc->ctrl.p, gen, (double*)sc->accum.p, aov, (Counters*)sc->counters.p);
+            else
+                hipLaunchKernelGGL(k_trace<false>, dim3(blocks), dim3(256), 0, sc->stream, sc->dev, F, qin, qout,
+                                   (GenCtrl*)sc->ctrl.p, gen, (double*)sc->accum.p, aov, (Counters*)nullptr);
+        }
+        const unsigned n_values = (unsigned)(n_local_px * 3);
+        hipLaunchKernelGGL(k_resolve, dim3((n_values + 255) / 256), dim3(256), 0, sc->stream,
+                           (const double*)sc->accum.p, (uint8_t*)sc->rgb.p, n_values);
+        HIP_TRY(hipEventRecord(sc->ev1, sc->stream));
+        HIP_TRY(hipGetLastError());
+        std::vector<GenCtrl> ctrl((size_t)G + 1);
+        HIP_TRY(hipMemcpyAsync(ctrl.data(), sc->ctrl.p, ctrl.size() * sizeof(GenCtrl), hipMemcpyDeviceToHost, sc->stream));
+        HIP_TRY(hipStreamSynchronize(sc->stream));
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, sc->ev0, sc->ev1));
+        kernel_ms += ms;
+        bool overflow = false;
+        uint32_t peak = 0;
+        for (const GenCtrl& c : ctrl) { overflow |= c.overflow != 0; peak = std::max(peak, c.count); }
+        if (!overflow) {
+            if (stats) {
+                stats->generations = (uint32_t)G;
+                stats->queue_overflows = overflows;
+            }
+            break;
+        }
+        overflows++;
+        int64_t want = std::max<int64_t>((int64_t)peak + (peak >> 3), (int64_t)sc->queue_capacity * 2);
+        sc->queue_capacity = (uint32_t)std::min<int64_t>(want, 0x7FFFFFF0);
+        if (overflows > 8) return fail(RTX_ENOMEM, "ray queues kept overflowing");
+    }
+
+    if (rgb_is_device) HIP_TRY(hipMemcpyAsync(rgb_out, sc->rgb.p, (size_t)n_local_px * 3, hipMemcpyDeviceToDevice, sc->stream));
+    else HIP_TRY(hipMemcpyAsync(rgb_out, sc->rgb.p, (size_t)n_local_px * 3, hipMemcpyDeviceToHost, sc->stream));
+    if (hit_ids) HIP_TRY(hipMemcpyAsync(hit_ids, sc->aov.p, (size_t)cam->width * cam->height * sizeof(rtx_hit_id), hipMemcpyDeviceToHost, sc->stream));
+    Counters ctr{};
+    if (sc->counters_on) HIP_TRY(hipMemcpyAsync(&ctr, sc->counters.p, sizeof ctr, hipMemcpyDeviceToHost, sc->stream));
+    HIP_TRY(hipStreamSynchronize(sc->stream));
+    if (stats) {
+        stats->rays = ctr.rays; stats->primary_rays = ctr.primary; stats->shadow_rays = ctr.shadow;
+        stats->secondary_rays = ctr.secondary; stats->node_visits = ctr.node_visits; stats->tri_tests = ctr.tri_tests;
+        stats->world_box_tests = ctr.world_box_tests; stats->object_space_traversals = ctr.object_traversals;
+        stats->tlas_node_visits = ctr.tlas_visits;
+        stats->kernel_ms = kernel_ms;
+        stats->total_ms = std::chrono::duration<double, std::milli>(std::chrono::high_resolution_clock::now() - wall0).count();
+    }
+    return RTX_OK;
+}
+
+}  // extern "C"

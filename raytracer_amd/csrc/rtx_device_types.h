@@ -1,0 +1,125 @@
+// Device-side (HBM) layout of a flattened scene.  Host code in rtx_core.hip fills these
+// from an rtx_scene_desc; the kernels read nothing else.
+//
+// Two-level layout:
+//   BLAS  -- per mesh, the reference's own binary BVH (bvh.cpp:187-258) re-packed so that
+//            one 128-byte record holds BOTH children's boxes of an inner node; leaves are
+//            ranges of a triangle array stored in leaf order (the order of
+//            MeshBVH::faceIndices), each triangle pre-gathered as (a, b-a, c-a).
+//   TLAS  -- a spatial BVH over the world boxes of the mesh instances, built here (the
+//            reference scans instances linearly, utils.cpp:756-790).  It only *selects
+//            candidates*; candidates are then processed in ascending instance index with
+//            the reference's own per-instance logic, because the result of the reference's
+//            loop depends on that order (utils.cpp:483-489,510 and 567-570).
+#pragma once
+#include <stdint.h>
+
+namespace rtxdev {
+
+// Inner BLAS node.  A child with count == 0 is another inner node (ref = node index);
+// count > 0 is a leaf owning triangles [ref, ref + count) of the global triangle array.
+struct Node {
+    double lmin[3], lmax[3], rmin[3], rmax[3];
+    int32_t lref, lcount, rref, rcount;
+    int32_t axis;          // BVHNode::splitAxis: near child = left iff dir[axis] >= 0
+    int32_t pad[3];
+};
+static_assert(sizeof(Node) == 128, "Node must be 128 bytes");
+
+// Hot triangle record: vertex a and the two edges (b - a), (c - a).
+struct Tri { double a[3], e1[3], e2[3]; };
+static_assert(sizeof(Tri) == 72, "Tri must be 72 bytes");
+
+struct Mesh {
+    double rmin[3], rmax[3];     // root box (tested before anything else, bvh.cpp:132 on node 0)
+    int32_t root_ref, root_count;
+    int32_t material, smooth, xform, n_faces;
+    int32_t has_vn, pad;
+};
+
+// TLAS inner node: child boxes + the index range of the instances below each child.
+struct TlasNode {
+    double lmin[3], lmax[3], rmin[3], rmax[3];
+    int32_t lref, lcount, rref, rcount;      // count > 0: leaf over tlas_order[ref .. ref+count)
+    int32_t lmin_idx, lmax_idx, rmin_idx, rmax_idx;
+};
+static_assert(sizeof(TlasNode) == 128, "TlasNode must be 128 bytes");
+
+struct Inst {
+    int32_t base_mesh, material;
+    int32_t xform;        // effective transform: the instance's own, else the base mesh's, else -1
+    int32_t pad;
+};
+
+struct Plane  { double n[3], a[3]; int32_t material, xform; };
+struct Sphere { double c[3], r;    int32_t material, xform; };
+struct FreeTri { double a[3], e1[3], e2[3], gn[3]; int32_t material, xform; };
+
+struct Material {
+    double ambient[3], diffuse[3], specular[3], mirror[3];
+    double phong, n, k;
+    double sigma[3];
+    int32_t type, is_mirror;
+};
+
+struct Light { double p[3], i[3]; };
+
+// Row-major 3x4 parts are what the kernels need; the 4th row is kept for the perspective
+// divide of transformPointFast (utils.cpp:100-104).
+struct Xform {
+    double m[16], inv[16], nrm[16];
+    double bmin[3], bmax[3];
+    int32_t has_bounds, pad;
+};
+
+struct Scene {
+    double bg[3], ambient[3];
+    double shadow_eps, isect_eps;
+    int32_t max_depth, cull;
+    int32_t n_lights, n_planes, n_spheres, n_ftris, n_meshes, n_insts;
+    const Material* materials;
+    const Light* lights;
+    const Xform* xforms;
+    const Plane* planes;
+    const Sphere* spheres;
+    const FreeTri* ftris;
+    const Mesh* meshes;
+    const Inst* insts;
+    const Node* nodes;
+    const Tri* tris;
+    const double* tri_gn;     // 3 per triangle: normalize((b-a) x (c-a))
+    const double* tri_vn;     // 9 per triangle (vertex normals of its corners) or null
+    const int32_t* tri_face;  // original face index of each triangle
+    const TlasNode* tlas;
+    const int32_t* tlas_order;
+    // TLAS root (may itself be a leaf)
+    double tl_min[3], tl_max[3];
+    int32_t tl_ref, tl_count, tl_min_idx, tl_max_idx;
+};
+
+// Per-frame camera basis, precomputed on the host with the arithmetic of utils.cpp:135-146.
+struct Frame {
+    double e[3], u[3], v[3], q[3];
+    double r_minus_l, t_minus_b;
+    int32_t width, height;
+    int32_t tile_w, tile_h, tiles_x, tile_first, tile_stride, n_local_pixels;
+};
+
+// Ray queue (structure of arrays).  kind: 0 = radiance ray, 1 = shadow ray.
+// meta = depth | kind << 8 | (beer_material + 1) << 9
+struct Queue {
+    double* ox; double* oy; double* oz;
+    double* dx; double* dy; double* dz;
+    double* wx; double* wy; double* wz;
+    double* aux;            // shadow rays: distance to the light
+    uint32_t* pixel;
+    uint32_t* meta;
+    uint32_t capacity;
+};
+
+struct Counters {
+    unsigned long long rays, primary, shadow, secondary;
+    unsigned long long node_visits, tri_tests, world_box_tests, object_traversals, tlas_visits;
+};
+
+}  // namespace rtxdev

@@ -1,0 +1,21 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def unit_scenes(tmp_path_factory):
+    """Deterministically generated unit scenes: name -> path of the .json file."""
+    from raytracer_amd import scenes
+    d = tmp_path_factory.mktemp("unit_scenes")
+    return scenes.write_unit_scenes(str(d))
