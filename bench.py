@@ -1,0 +1,296 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path: one step = one frame of the workload through rtx_render.
+
+Metric (BASELINE.json): Mrays/s and ms/frame.  A ray is one closest-hit query the reference
+semantics require (one intersect() call, utils.cpp:671, not counting calls whose result
+computePixelColor discards); the per-frame ray count R is taken from the device's own
+counters in an untimed pass and is, by construction and by test, the count the CPU
+restatement produces.
+
+N = 1: the dragon_metal stand-in (one 1.8 M-face smooth conductor mesh + a Lambertian
+instance of it + ground, 1920x1152, depth 6) unless --workload says otherwise.
+N > 1: whole frames are sharded -- rank r renders orbit frame r of the same scene every
+step, no collective on the data path (weak scaling); `--mode tiles` instead splits ONE
+frame into interleaved tiles and gathers them on rank 0 over RCCL (strong scaling).
+
+Prints one JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import math
+import os
+import shutil
+import subprocess
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+# Device-layout record sizes (raytracer_amd/csrc/rtx_device_types.h): what one unit of
+# traversal work has to read, used for the algorithmic-bytes figure of the roofline.
+NODE_BYTES = 128      # one inner-node visit = both children's boxes + links
+TRI_BYTES = 72        # one triangle test = (a, e1, e2)
+BOX_BYTES = 48        # one world-AABB test
+XFORM_BYTES = 128     # one ray taken to object space = the inverse matrix
+RAY_BYTES = 88        # one queue item (written once, read once)
+HBM_PEAK_GBS = 8000.0
+
+
+def algorithmic_bytes(st) -> int:
+    return (NODE_BYTES * st["node_visits"] + TRI_BYTES * st["tri_tests"] + BOX_BYTES * st["world_box_tests"]
+            + XFORM_BYTES * st["object_space_traversals"] + NODE_BYTES * st["tlas_node_visits"]
+            + 2 * RAY_BYTES * (st["rays"] - st["primary_rays"]) + 24 * st["primary_rays"])
+
+
+def scene_cache_dir():
+    d = os.environ.get("RTX_BENCH_SCENES", os.path.join(tempfile.gettempdir(), f"rtx_bench_scenes_{os.getuid()}"))
+    os.makedirs(d, exist_ok=True)
+    return d
+
+
+def make_workload(name: str, d: str, frame: int = 0, n_frames: int = 360):
+    """-> (scene json path, description string)"""
+    from raytracer_amd import scenes
+    if name == "dragon_metal":
+        p = os.path.join(d, "dragon_metal.json")
+        if not os.path.exists(p):
+            scenes.scene_dragon_metal(d, faces=1_800_000, res=(1920, 1152), name="dragon_metal")
+        return p, "dragon_metal stand-in: 1.8M-face smooth conductor PLY mesh + Lambertian instance + ground, 1920x1152, depth 6, 2 lights"
+    if name == "dragon_metal_small":
+        p = os.path.join(d, "dragon_metal_small.json")
+        if not os.path.exists(p):
+            scenes.scene_dragon_metal(d, faces=100_000, res=(480, 288), name="dragon_metal_small")
+        return p, "dragon_metal stand-in, reduced: 100k faces, 480x288"
+    if name == "marching_dragons":
+        p = os.path.join(d, "marching_dragons.json")
+        if not os.path.exists(p):
+            scenes.scene_marching(d, faces=400_000, res=(1920, 1080), name="marching_dragons")
+        return p, "marching_dragons stand-in: 400k-face base mesh + 8 transformed instances, 1920x1080"
+    if name == "grass_desert":
+        p = os.path.join(d, "grass_desert.json")
+        if not os.path.exists(p):
+            scenes.scene_grass(d, n_instances=10_000, res=(3840, 2160), name="grass_desert")
+        return p, "grass_desert stand-in: 10k instanced blade clumps, 3840x2160"
+    if name == "metal_glass_plates":
+        p = os.path.join(d, "metal_glass_plates.json")
+        if not os.path.exists(p):
+            scenes.scene_plates(d, res=(800, 800), name="metal_glass_plates")
+        return p, "metal_glass_plates stand-in: plane, spheres, dielectric boxes of free triangles, 800x800"
+    if name == "camera_around_david":
+        p = os.path.join(d, f"davids_camera_{frame:03d}.json")
+        if not os.path.exists(p):
+            scenes.scene_david_frame(d, frame, n_frames=n_frames, faces=100_000, res=(800, 800), name="davids_camera")
+        return p, "camera_around_david stand-in: 100k-face mesh + mirror ground, 800x800, 360-frame orbit"
+    raise SystemExit(f"unknown workload {name}")
+
+
+def orbit_camera(cam, angle_deg: float):
+    """Rotate the camera about the world y axis through the origin (whole-frame sharding
+    gives every rank its own frame of an orbit around the same scene)."""
+    from raytracer_amd import Camera
+    a = math.radians(angle_deg)
+    c, s = math.cos(a), math.sin(a)
+    out = Camera()
+    C.memmove(C.byref(out), C.byref(cam), C.sizeof(Camera))
+    for name in ("position", "gaze", "up"):
+        v = getattr(cam, name)
+        x, y, z = v[0], v[1], v[2]
+        getattr(out, name)[:] = [c * x + s * z, y, -s * x + c * z]
+    return out
+
+
+def cpu_reference_baseline(scene_json: str, rays: int):
+    """Time the unmodified reference renderer (oracle/_ref/raytracer_ref, built from the
+    reference's own sources) on this host: `./raytracer <scene> -b`, multithreaded default
+    = min(4, nproc) threads (raytracer.cpp:99-100).  Reads renderTimeMs from its results
+    JSON (raytracer.cpp:269-282)."""
+    ref = os.path.join(ROOT, "oracle", "_ref", "raytracer_ref")
+    if not os.access(ref, os.X_OK):
+        return None
+    work = tempfile.mkdtemp(prefix="rtx_ref_")
+    try:
+        os.makedirs(os.path.join(work, "run"))
+        os.makedirs(os.path.join(work, "my_outputs_hw2"))
+        t0 = time.time()
+        r = subprocess.run([ref, scene_json, "-b"], cwd=os.path.join(work, "run"), stdout=subprocess.DEVNULL,
+                           stderr=subprocess.DEVNULL, timeout=900)
+        wall = time.time() - t0
+        if r.returncode != 0:
+            return None
+        res = [f for f in os.listdir(os.path.join(work, "my_outputs_hw2")) if f.endswith("_results.json")]
+        if not res:
+            return None
+        with open(os.path.join(work, "my_outputs_hw2", res[0])) as f:
+            j = json.load(f)
+        render_ms = float(j["renderTimeMs"])
+        return {"value": rays / render_ms / 1e3, "unit": "Mrays/s", "cores": min(4, os.cpu_count() or 4),
+                "kind": "reference", "ms_per_frame": render_ms, "preprocess_ms": float(j["preprocessingTimeMs"]),
+                "host_cpus": os.cpu_count(),
+                "sample": f"whole frame once, ./raytracer <scene> -b (reference caps itself at 4 threads); process wall {wall:.1f} s"}
+    except Exception:
+        return None
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="dragon_metal")
+    ap.add_argument("--mode", choices=["frames", "tiles"], default="frames")
+    ap.add_argument("--tile", default="64x8")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import raytracer_amd as rt
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: there is no CPU path behind the C-ABI")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    d = scene_cache_dir()
+    if rank == 0:
+        path, descr = make_workload(args.workload, d)
+    barrier()
+    path, descr = make_workload(args.workload, d)
+
+    t0 = time.time()
+    hs = rt.HostScene(path)
+    t_load = time.time() - t0
+    t0 = time.time()
+    ds = rt.DeviceScene(hs.desc, local_rank)
+    t_upload = time.time() - t0
+    cam0, _ = hs.camera(0)
+    tw, th = (int(x) for x in args.tile.split("x"))
+
+    if args.mode == "frames":
+        cam = orbit_camera(cam0, 360.0 * rank / max(world, 1) if world > 1 else 0.0)
+    else:
+        cam = cam0
+
+    # ---- untimed counting pass: rays and traversal work of this rank's step ----------------
+    ds.set_counters(True)
+    if args.mode == "frames":
+        _, _, cst = ds.render(cam)
+    else:
+        _, cst = ds.render_tiles(cam, tw, th, rank, world)
+    ds.set_counters(False)
+    rays_rank = int(cst["rays"])
+    alg_bytes_rank = algorithmic_bytes(cst)
+
+    frame = np.empty((cam.height, cam.width, 3), dtype=np.uint8)
+    gather_buf = None
+    my_bytes = ds.tile_bytes(cam, tw, th, rank, world) if args.mode == "tiles" else 0
+    if args.mode == "tiles":
+        sizes = [ds.tile_bytes(cam, tw, th, r, world) for r in range(world)]
+        pad = max(sizes)
+        my_dev = torch.empty(pad, dtype=torch.uint8, device="cuda")
+        if rank == 0 and world > 1:
+            gather_buf = [torch.empty(pad, dtype=torch.uint8, device="cuda") for _ in range(world)]
+
+    def step():
+        if args.mode == "frames":
+            _, _, st = ds.render(cam)
+            return st
+        _, st = ds.render_tiles(cam, tw, th, rank, world, out_ptr=my_dev.data_ptr(), out_is_device=True)
+        if world > 1:
+            dist.gather(my_dev, gather_buf, dst=0)
+        if rank == 0:
+            parts = gather_buf if world > 1 else [my_dev]
+            for r, t in enumerate(parts):
+                rt.unpack_tiles(t[:sizes[r]].cpu().numpy(), cam.width, cam.height, tw, th, r, world, frame)
+        return st
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    kernel_ms = 0.0
+    for _ in range(args.steps):
+        st = step()
+        kernel_ms += st["kernel_ms"]
+    barrier()
+    elapsed = time.perf_counter() - t0
+
+    el = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    tot = torch.tensor([float(rays_rank), float(alg_bytes_rank)], dtype=torch.float64, device="cuda")
+    if dist is not None:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+    elapsed = float(el.item())
+    rays_step = float(tot[0].item())
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        mrays = rays_step * args.steps / elapsed / 1e6
+        G = hs.desc.contents.max_recursion_depth + 2
+        k_ms_frame = kernel_ms / args.steps                    # rank 0's frame, all k_trace launches
+        achieved = alg_bytes_rank / (k_ms_frame * 1e-3) / 1e9 if k_ms_frame > 0 else 0.0
+        traffic = None
+        tfile = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tfile):
+            try:
+                with open(tfile) as f:
+                    tj = json.load(f)
+                if tj.get("workload") == args.workload:
+                    traffic = tj.get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "Mrays/s (ms/frame in ms_per_step)", "value": mrays, "unit": "Mrays/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": "weak" if args.mode == "frames" else "strong",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": args.workload, "description": descr, "mode": args.mode,
+                       "resolution": [cam.width, cam.height], "rays_per_step": rays_step,
+                       "rays_per_pixel": rays_rank / (cam.width * cam.height) if args.mode == "frames" else None,
+                       "frames_per_step": world if args.mode == "frames" else 1,
+                       "host_load_s": t_load, "scene_upload_s": t_upload},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel": "k_trace", "launches_per_frame": G,
+                         "avg_launch_ms": k_ms_frame / G, "kernel_ms_per_frame": k_ms_frame,
+                         "algorithmic_bytes_per_launch": alg_bytes_rank / G,
+                         "algorithmic_bytes_per_ray": alg_bytes_rank / max(rays_rank, 1),
+                         "node_visits": int(cst["node_visits"]), "tri_tests": int(cst["tri_tests"])},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            cb = cpu_reference_baseline(path, rays_rank)
+            if cb is not None:
+                out["cpu_baseline"] = cb
+                out["config"]["speedup_vs_cpu_reference_ms_per_frame"] = cb["ms_per_frame"] / ms_per_step
+        print(json.dumps(out), flush=True)
+    ds.close()
+    hs.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

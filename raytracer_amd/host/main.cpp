@@ -1,0 +1,109 @@
+// raytracer_amd -- command-line host with the reference's flags (raytracer.cpp:173-210)
+// that renders on the MI355X core instead of the CPU loops.
+//
+//   raytracer_amd <scene.json> [more.json ...] [-b [0|1]] [-m [0|1]] [-c [0|1]]
+//                 [--device D] [--shard R/N] [--out DIR] [--png] [--quiet]
+//
+// -b  BVH on/off (default on; `-b` alone = on).  Off ships meshes without a BVH; the device
+//     then tests every face of a mesh in face order, like the reference's brute-force loop.
+// -m  accepted for compatibility (the reference's thread switch); it has no effect here.
+// -c  back-face culling (default off; `-c` alone = off, `-c 1` = on), as in the reference.
+// --shard R/N  render only scene files i with i % N == R (whole-frame sharding of an
+//     animation across N processes, one per GPU; no communication needed).
+//
+// For every camera it writes <out>/<ImageName stem>.ppm (ASCII P3, byte-identical layout to
+// scene.cpp:675-697), optionally a .png, and <stem>_results.json with the reference's keys
+// (raytracer.cpp:269-282) plus device timings.
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "rtx_amd.h"
+#include "rtx_host.h"
+
+int main(int argc, char** argv) {
+    std::vector<std::string> scenes;
+    bool use_bvh = true, cull = false, multithreaded = true, png = false, quiet = false;
+    int device = 0, shard_r = 0, shard_n = 1;
+    std::string out_dir = "../my_outputs_hw2/";            // raytracer.cpp:13
+    auto opt01 = [&](int& i, bool bare_value, bool& target) {
+        if (i + 1 < argc && (!strcmp(argv[i + 1], "0") || !strcmp(argv[i + 1], "1"))) { target = atoi(argv[++i]) != 0; }
+        else target = bare_value;
+    };
+    for (int i = 1; i < argc; i++) {
+        if (!strcmp(argv[i], "-m")) opt01(i, false, multithreaded);
+        else if (!strcmp(argv[i], "-b")) opt01(i, true, use_bvh);
+        else if (!strcmp(argv[i], "-c") || !strcmp(argv[i], "--no-cull")) opt01(i, false, cull);
+        else if (!strcmp(argv[i], "--device") && i + 1 < argc) device = atoi(argv[++i]);
+        else if (!strcmp(argv[i], "--out") && i + 1 < argc) { out_dir = argv[++i]; if (!out_dir.empty() && out_dir.back() != '/') out_dir += '/'; }
+        else if (!strcmp(argv[i], "--shard") && i + 1 < argc) { if (sscanf(argv[++i], "%d/%d", &shard_r, &shard_n) != 2 || shard_n < 1 || shard_r < 0 || shard_r >= shard_n) { fprintf(stderr, "bad --shard\n"); return 2; } }
+        else if (!strcmp(argv[i], "--png")) png = true;
+        else if (!strcmp(argv[i], "--quiet")) quiet = true;
+        else scenes.push_back(argv[i]);
+    }
+    if (scenes.empty()) {
+        fprintf(stderr, "usage: raytracer_amd <scene.json>... [-b [0|1]] [-m [0|1]] [-c [0|1]] [--device D] [--shard R/N] [--out DIR] [--png]\n");
+        return 2;
+    }
+    (void)multithreaded;
+    int rc_all = 0;
+    for (size_t si = 0; si < scenes.size(); si++) {
+        if ((int)(si % (size_t)shard_n) != shard_r) continue;
+        rtx_host_scene* hs = nullptr;
+        if (rtx_host_load(scenes[si].c_str(), use_bvh, cull, &hs) != 0) {
+            fprintf(stderr, "%s: %s\n", scenes[si].c_str(), rtx_host_last_error());
+            rc_all = 1;
+            continue;
+        }
+        double parse_ms = 0, pre_ms = 0;
+        rtx_host_timings(hs, &parse_ms, &pre_ms);
+        auto t0 = std::chrono::high_resolution_clock::now();
+        rtx_scene* ds = nullptr;
+        if (rtx_scene_create(rtx_host_desc(hs), device, &ds) != RTX_OK) {
+            fprintf(stderr, "%s: %s\n", scenes[si].c_str(), rtx_last_error());
+            rtx_host_free(hs);
+            return 1;                                        // no device: nothing else can work either
+        }
+        double upload_ms = std::chrono::duration<double, std::milli>(std::chrono::high_resolution_clock::now() - t0).count();
+        double total_ms = pre_ms;
+        for (int k = 0; k < rtx_host_camera_count(hs); k++) {
+            rtx_camera cam;
+            char name[512];
+            rtx_host_camera(hs, k, &cam, name, sizeof name);
+            std::vector<uint8_t> img((size_t)cam.width * cam.height * 3);
+            rtx_stats st;
+            if (rtx_render(ds, &cam, cam.width, cam.height, 0, 1, img.data(), 0, nullptr, &st) != RTX_OK) {
+                fprintf(stderr, "%s: %s\n", scenes[si].c_str(), rtx_last_error());
+                rc_all = 1;
+                break;
+            }
+            total_ms += st.total_ms;
+            std::string base = out_dir + name;
+            if (rtx_host_write_ppm(base.c_str(), img.data(), cam.width, cam.height) != 0) {
+                fprintf(stderr, "%s\n", rtx_host_last_error());
+                rc_all = 1;
+            }
+            std::string stem = base.substr(0, base.find_last_of('.'));
+            if (png) rtx_host_write_png((stem + ".png").c_str(), img.data(), cam.width, cam.height);
+            FILE* f = fopen((stem + "_results.json").c_str(), "w");
+            if (f) {
+                fprintf(f, "{\n    \"enableBackFaceCulling\": %s,\n    \"isMultiThreaded\": %s,\n"
+                           "    \"preprocessingTimeMs\": %.3f,\n    \"renderTimeMs\": %.3f,\n    \"sceneName\": \"%s\",\n"
+                           "    \"totalTimeMs\": %.3f,\n    \"useBVH\": %s,\n    \"device\": \"hip:%d\",\n"
+                           "    \"kernelTimeMs\": %.3f,\n    \"parseTimeMs\": %.3f,\n    \"uploadTimeMs\": %.3f\n}",
+                        cull ? "true" : "false", multithreaded ? "true" : "false", pre_ms, st.total_ms, name, total_ms,
+                        use_bvh ? "true" : "false", device, st.kernel_ms, parse_ms, upload_ms);
+                fclose(f);
+            }
+            if (!quiet)
+                printf("%s: %dx%d rendered in %.3f ms (kernels %.3f ms), preprocess %.1f ms, upload %.1f ms\n", name,
+                       cam.width, cam.height, st.total_ms, st.kernel_ms, pre_ms, upload_ms);
+        }
+        rtx_scene_destroy(ds);
+        rtx_host_free(hs);
+    }
+    return rc_all;
+}

@@ -163,7 +163,7 @@ def scene_tiny(out_dir, res=(64, 48)):
         "IntersectionTestEpsilon": "1e-6",
         "Cameras": {"Camera": _camera((0, 3, 10), (0, 0, 0), (0, 1, 0), 45, res, "tiny.png")},
         "Lights": {"AmbientLight": "25 25 25",
-                   "PointLight": [_light(1, (5, 8, 5), (60000, 60000, 60000))]},
+                   "PointLight": [_light(1, (5, 8, 5), (20000, 20000, 20000))]},
         "Materials": {"Material": [
             _mat(1, (1, 1, 1), (0.6, 0.6, 0.6), (0.2, 0.2, 0.2), phong=10),
             _mat(2, (0, 0, 0), (0, 0, 0), (0, 0, 0), phong=50, mirror=(0.9, 0.8, 0.7),
@@ -319,8 +319,8 @@ def scene_plates(out_dir, res=(800, 800), name="metal_glass_plates"):
         "IntersectionTestEpsilon": "1e-6",
         "Cameras": {"Camera": _camera((0.3, 2.6, 7.5), (0, 0.8, 0), (0, 1, 0), 38, res, name + ".png")},
         "Lights": {"AmbientLight": "25 25 25",
-                   "PointLight": [_light(1, (4, 7, 6), (50000, 50000, 50000)),
-                                  _light(2, (-5, 5, 2), (25000, 25000, 30000))]},
+                   "PointLight": [_light(1, (4, 7, 6), (18000, 18000, 18000)),
+                                  _light(2, (-5, 5, 2), (9000, 9000, 11000))]},
         "Materials": {"Material": [
             _mat(1, (1, 1, 1), (0.5, 0.5, 0.5), (0.2, 0.2, 0.2), phong=10),
             _mat(2, (1, 1, 1), (0.7, 0.15, 0.15), (0.6, 0.6, 0.6), phong=60),
@@ -358,8 +358,8 @@ def scene_dragon_metal(out_dir, faces=1_800_000, res=(1920, 1152), name="dragon_
         "IntersectionTestEpsilon": "1e-6",
         "Cameras": {"Camera": _camera((0.8, 3.2, 8.5), (1.2, 1.5, 0), (0, 1, 0), 45, res, name + ".png")},
         "Lights": {"AmbientLight": "25 25 25",
-                   "PointLight": [_light(1, (6, 10, 7), (110000, 110000, 110000)),
-                                  _light(2, (-7, 6, 4), (40000, 40000, 45000))]},
+                   "PointLight": [_light(1, (6, 10, 7), (35000, 35000, 35000)),
+                                  _light(2, (-7, 6, 4), (14000, 14000, 16000))]},
         "Materials": {"Material": [
             _mat(1, (1, 1, 1), (0.5, 0.5, 0.5), (0.1, 0.1, 0.1), phong=5),
             _mat(2, (0, 0, 0), (0, 0, 0), (0, 0, 0), phong=80, mirror=(0.95, 0.8, 0.45),
@@ -407,8 +407,8 @@ def scene_marching(out_dir, faces=400_000, res=(1920, 1080), name="marching_drag
         "IntersectionTestEpsilon": "1e-6",
         "Cameras": {"Camera": _camera((0, 7.5, 12.5), (0, 0.8, 0), (0, 1, 0), 40, res, name + ".png")},
         "Lights": {"AmbientLight": "25 25 25",
-                   "PointLight": [_light(1, (8, 12, 8), (160000, 160000, 160000)),
-                                  _light(2, (-9, 8, 2), (60000, 60000, 70000))]},
+                   "PointLight": [_light(1, (8, 12, 8), (55000, 55000, 55000)),
+                                  _light(2, (-9, 8, 2), (20000, 20000, 24000))]},
         "Materials": {"Material": mats},
         "Transformations": {"Translation": trans, "Scaling": scalings, "Rotation": rots},
         "VertexData": {"_data": _flat(np.array(_ground(), dtype=np.float64))},
@@ -436,8 +436,8 @@ def scene_david_frame(out_dir, frame, n_frames=360, faces=100_000, res=(800, 800
         "IntersectionTestEpsilon": "1e-6",
         "Cameras": {"Camera": _camera(pos, (0, 1.6, 0), (0, 1, 0), 40, res, f"{name}_{frame:03d}.png")},
         "Lights": {"AmbientLight": "25 25 25",
-                   "PointLight": [_light(1, (5, 9, 6), (90000, 90000, 90000)),
-                                  _light(2, (-6, 5, -4), (40000, 40000, 40000))]},
+                   "PointLight": [_light(1, (5, 9, 6), (30000, 30000, 30000)),
+                                  _light(2, (-6, 5, -4), (14000, 14000, 14000))]},
         "Materials": {"Material": [
             _mat(1, (1, 1, 1), (0.5, 0.5, 0.5), (0.1, 0.1, 0.1), phong=5, mirror=(0.3, 0.3, 0.3)),
             _mat(2, (1, 1, 1), (0.75, 0.72, 0.65), (0.3, 0.3, 0.3), phong=30)]},
