@@ -144,7 +144,8 @@ def load_host_lib():
 def load_amd_lib():
     """Load the device library.  Raises OSError when it (or the HIP runtime) is missing:
     there is no CPU fallback behind this API."""
-    lib = C.CDLL(os.path.join(LIB_DIR, "librtx_amd.so"))
+    # RTX_AMD_LIB selects another build of the same library (kernel experiments).
+    lib = C.CDLL(os.environ.get("RTX_AMD_LIB") or os.path.join(LIB_DIR, "librtx_amd.so"))
     lib.rtx_scene_create.argtypes = [C.POINTER(SceneDesc), C.c_int, C.POINTER(C.c_void_p)]
     lib.rtx_scene_create.restype = C.c_int
     lib.rtx_scene_update_lights.argtypes = [C.c_void_p, C.POINTER(Light), C.c_int32]

@@ -596,13 +596,23 @@ k_trace(const Scene S, const Frame F, const Queue qin, const Queue qout, GenCtrl
     Tally tl = {0, 0, 0, 0, 0};
     unsigned n_rays = 0, n_primary = 0, n_shadow = 0, n_secondary = 0;
 
+    // Rays claimed per wave and fetch: 64 when the generation can fill the whole grid,
+    // fewer when it cannot -- a thin generation (deep reflection chains) is latency bound,
+    // and spreading its rays over more waves shortens the slowest wave.
+    unsigned batch = 64u;
+    if (gen != 0) {
+        const unsigned waves = gridDim.x * (blockDim.x >> 6);
+        batch = (n_in + waves - 1u) / waves;
+        batch = batch < 1u ? 1u : (batch > 64u ? 64u : batch);
+    }
+
     while (true) {
         unsigned base = 0;
-        if (lane == 0) base = atomicAdd(&me->head, 64u);
+        if (lane == 0) base = atomicAdd(&me->head, batch);
         base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
         if (base >= n_in) break;
         const unsigned idx = base + lane;
-        bool active = idx < n_in;
+        bool active = lane < batch && idx < n_in;
 
         V3 o = mk(0, 0, 0), d = mk(0, 0, 1), W = mk(1, 1, 1);
         double aux = 0.0;
