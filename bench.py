@@ -277,7 +277,10 @@ def main():
                          "avg_launch_ms": k_ms_frame / G, "kernel_ms_per_frame": k_ms_frame,
                          "algorithmic_bytes_per_launch": alg_bytes_rank / G,
                          "algorithmic_bytes_per_ray": alg_bytes_rank / max(rays_rank, 1),
-                         "node_visits": int(cst["node_visits"]), "tri_tests": int(cst["tri_tests"])},
+                         "node_visits": int(cst["node_visits"]), "tri_tests": int(cst["tri_tests"]),
+                         "simt_lanes_per_inner_step": cst["wave_inner_lanes"] / max(cst["wave_inner_steps"], 1),
+                         "simt_lanes_per_leaf_step": cst["wave_leaf_lanes"] / max(cst["wave_leaf_steps"], 1),
+                         "wave_inner_steps": int(cst["wave_inner_steps"]), "wave_leaf_steps": int(cst["wave_leaf_steps"])},
         }
         if world == 1 and not args.no_cpu_baseline:
             cb = cpu_reference_baseline(path, rays_rank)

@@ -148,6 +148,9 @@ typedef struct rtx_stats {
     double kernel_ms;          /* HIP-event time of all kernels of the frame              */
     double total_ms;           /* kernels + download of the image                         */
     uint32_t generations, queue_overflows;
+    /* SIMT occupancy of the traversal (counters on): wave-level inner-node / triangle steps
+     * and the number of lanes that did useful work in them (64 per step is the ideal). */
+    uint64_t wave_inner_steps, wave_inner_lanes, wave_leaf_steps, wave_leaf_lanes;
 } rtx_stats;
 
 typedef struct rtx_scene rtx_scene;   /* opaque: owns the device copy of the scene */

@@ -97,7 +97,9 @@ class Stats(C.Structure):
                 ("tri_tests", C.c_uint64), ("world_box_tests", C.c_uint64),
                 ("object_space_traversals", C.c_uint64), ("tlas_node_visits", C.c_uint64),
                 ("kernel_ms", C.c_double), ("total_ms", C.c_double),
-                ("generations", C.c_uint32), ("queue_overflows", C.c_uint32)]
+                ("generations", C.c_uint32), ("queue_overflows", C.c_uint32),
+                ("wave_inner_steps", C.c_uint64), ("wave_inner_lanes", C.c_uint64),
+                ("wave_leaf_steps", C.c_uint64), ("wave_leaf_lanes", C.c_uint64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

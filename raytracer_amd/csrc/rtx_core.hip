@@ -70,8 +70,8 @@ struct rtx_scene {
     int64_t queue_limit = (int64_t)32 << 30;
     uint32_t queue_capacity = 0;    // rays per queue, grows on overflow and is then kept
     DevBuf materials, lights, xforms, planes, spheres, ftris, meshes, insts, nodes, tris, tri_gn, tri_vn,
-        tri_face, tlas, tlas_order;
-    DevBuf accum, rgb, aov, ctrl, counters, queue[2];
+        tlas, tlas_order;
+    DevBuf accum, rgb, aov, ctrl, counters, queue[2], hitbuf;
     ~rtx_scene() {
         if (ev0) (void)hipEventDestroy(ev0);
         if (ev1) (void)hipEventDestroy(ev1);
@@ -86,7 +86,6 @@ struct Flat {
     std::vector<Node> nodes;
     std::vector<Tri> tris;
     std::vector<double> tri_gn, tri_vn;
-    std::vector<int32_t> tri_face;
     std::vector<Mesh> meshes;
     bool any_vn = false;
 };
@@ -101,6 +100,7 @@ int push_tri(const rtx_scene_desc& d, const rtx_mesh& m, int face, Flat& F) {
     const double* c = d.vertices + 3 * (size_t)f[2];
     Tri t;
     for (int k = 0; k < 3; k++) { t.a[k] = a[k]; t.e1[k] = b[k] - a[k]; t.e2[k] = c[k] - a[k]; }
+    t.face = face; t.pad = 0;
     F.tris.push_back(t);
     // geometricNormal = normalize(crossProduct(e1, e2)), utils.cpp:319-321
     double nx = t.e1[1] * t.e2[2] - t.e1[2] * t.e2[1];
@@ -108,7 +108,6 @@ int push_tri(const rtx_scene_desc& d, const rtx_mesh& m, int face, Flat& F) {
     double nz = t.e1[0] * t.e2[1] - t.e1[1] * t.e2[0];
     double len = std::sqrt(nx * nx + ny * ny + nz * nz);
     F.tri_gn.push_back(nx / len); F.tri_gn.push_back(ny / len); F.tri_gn.push_back(nz / len);
-    F.tri_face.push_back(face);
     if (m.smooth && m.vertex_normals)
         for (int k = 0; k < 3; k++)
             for (int q = 0; q < 3; q++) F.tri_vn.push_back(m.vertex_normals[3 * (size_t)f[k] + q]);
@@ -381,7 +380,6 @@ int build_scene(rtx_scene& sc, const rtx_scene_desc& d) {
         // no smooth mesh: keep has_vn = 0 everywhere, nothing to upload
         S.tri_vn = nullptr;
     }
-    HIP_TRY(sc.tri_face.upload(F.tri_face)); S.tri_face = (const int32_t*)sc.tri_face.p;
     HIP_TRY(sc.tlas.upload(tlas));        S.tlas = (const TlasNode*)sc.tlas.p;
     HIP_TRY(sc.tlas_order.upload(order)); S.tlas_order = (const int32_t*)sc.tlas_order.p;
     return RTX_OK;
@@ -412,6 +410,19 @@ Queue make_queue(void* base, uint32_t cap) {
     return q;
 }
 constexpr size_t kRayBytes = 10 * 8 + 2 * 4;
+constexpr size_t kHitBytes = 10 * 8 + 4;
+
+HitBuf make_hitbuf(void* base, size_t cap) {
+    HitBuf h;
+    char* p = (char*)base;
+    auto take = [&](size_t elem) { void* r = p; p += cap * elem; return r; };
+    h.dist = (double*)take(8);
+    h.px = (double*)take(8); h.py = (double*)take(8); h.pz = (double*)take(8);
+    h.gx = (double*)take(8); h.gy = (double*)take(8); h.gz = (double*)take(8);
+    h.sx = (double*)take(8); h.sy = (double*)take(8); h.sz = (double*)take(8);
+    h.code = (int32_t*)take(4);
+    return h;
+}
 
 }  // namespace
 
@@ -541,7 +552,7 @@ int rtx_render(rtx_scene* sc, const rtx_camera* cam, int32_t tw, int32_t th, int
     const int64_t n_items0 = (int64_t)g.n_sel * blocks_per_tile * 64;
     const int64_t n_local_px = (int64_t)g.n_sel * tw * th;
     if (n_items0 > (int64_t)0x7FFFFFF0 || n_local_px * 3 > (int64_t)0x7FFFFFF0) return fail(RTX_ELIMIT, "frame too large for one call");
-    F.n_local_pixels = (int32_t)n_items0;
+    F.n_items0 = (int32_t)n_items0;
 
     const int G = sc->dev.max_depth + 2;
     HIP_TRY(sc->accum.ensure((size_t)n_local_px * 3 * sizeof(double)));
@@ -572,7 +583,10 @@ int rtx_render(rtx_scene* sc, const rtx_camera* cam, int32_t tw, int32_t th, int
         }
         HIP_TRY(sc->queue[0].ensure((size_t)sc->queue_capacity * kRayBytes));
         HIP_TRY(sc->queue[1].ensure((size_t)sc->queue_capacity * kRayBytes));
+        const size_t hit_cap = std::max<size_t>(sc->queue_capacity, (size_t)n_items0);
+        HIP_TRY(sc->hitbuf.ensure(hit_cap * kHitBytes));
         Queue q[2] = {make_queue(sc->queue[0].p, sc->queue_capacity), make_queue(sc->queue[1].p, sc->queue_capacity)};
+        const HitBuf hb = make_hitbuf(sc->hitbuf.p, hit_cap);
 
         HIP_TRY(hipMemsetAsync(sc->ctrl.p, 0, (size_t)(G + 1) * sizeof(GenCtrl), sc->stream));
         HIP_TRY(hipMemsetAsync(sc->accum.p, 0, (size_t)n_local_px * 3 * sizeof(double), sc->stream));
@@ -581,15 +595,19 @@ int rtx_render(rtx_scene* sc, const rtx_camera* cam, int32_t tw, int32_t th, int
         for (int gen = 0; gen < G; gen++) {
             unsigned blocks = persistent_blocks;
             if (gen == 0) blocks = (unsigned)std::min<int64_t>(persistent_blocks, (n_items0 + 255) / 256);
-            const Queue& qin = q[(gen + 1) & 1];
-            const Queue& qout = q[gen & 1];
+            const Queue& qin = q[(gen + 1) & 1];     // rays of this generation
+            const Queue& qout = q[gen & 1];          // rays it spawns
             rtx_hit_id* aov = (gen == 0 && hit_ids) ? (rtx_hit_id*)sc->aov.p : nullptr;
             if (sc->counters_on)
-                hipLaunchKernelGGL(k_trace<true>, dim3(blocks), dim3(256), 0, sc->stream, sc->dev, F, qin, qout,
+                hipLaunchKernelGGL(k_trace<true>, dim3(blocks), dim3(256), 0, sc->stream, sc->dev, F, qin, hb,
                                    (GenCtrl*)sc->ctrl.p, gen, (double*)sc->accum.p, aov, (Counters*)sc->counters.p);
             else
-                hipLaunchKernelGGL(k_trace<false>, dim3(blocks), dim3(256), 0, sc->stream, sc->dev, F, qin, qout,
+                hipLaunchKernelGGL(k_trace<false>, dim3(blocks), dim3(256), 0, sc->stream, sc->dev, F, qin, hb,
                                    (GenCtrl*)sc->ctrl.p, gen, (double*)sc->accum.p, aov, (Counters*)nullptr);
+            // the last generation holds shadow rays only: nothing left to shade
+            if (gen + 1 < G)
+                hipLaunchKernelGGL(k_shade, dim3(blocks), dim3(256), 0, sc->stream, sc->dev, F, qin, qout, hb,
+                                   (GenCtrl*)sc->ctrl.p, gen, (double*)sc->accum.p);
         }
         const unsigned n_values = (unsigned)(n_local_px * 3);
         hipLaunchKernelGGL(k_resolve, dim3((n_values + 255) / 256), dim3(256), 0, sc->stream,
@@ -604,7 +622,10 @@ int rtx_render(rtx_scene* sc, const rtx_camera* cam, int32_t tw, int32_t th, int
         kernel_ms += ms;
         bool overflow = false;
         uint32_t peak = 0;
-        for (const GenCtrl& c : ctrl) { overflow |= c.overflow != 0; peak = std::max(peak, c.count); }
+        for (const GenCtrl& c : ctrl) {
+            overflow |= c.overflow != 0;
+            peak = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(peak, (c.counts & 0xFFFFFFFFull) + (c.counts >> 32)), 0x7FFFFFF0ull);
+        }
         if (!overflow) {
             if (stats) {
                 stats->generations = (uint32_t)G;
@@ -629,6 +650,8 @@ int rtx_render(rtx_scene* sc, const rtx_camera* cam, int32_t tw, int32_t th, int
         stats->secondary_rays = ctr.secondary; stats->node_visits = ctr.node_visits; stats->tri_tests = ctr.tri_tests;
         stats->world_box_tests = ctr.world_box_tests; stats->object_space_traversals = ctr.object_traversals;
         stats->tlas_node_visits = ctr.tlas_visits;
+        stats->wave_inner_steps = ctr.inner_steps; stats->wave_inner_lanes = ctr.inner_lanes;
+        stats->wave_leaf_steps = ctr.leaf_steps; stats->wave_leaf_lanes = ctr.leaf_lanes;
         stats->kernel_ms = kernel_ms;
         stats->total_ms = std::chrono::duration<double, std::milli>(std::chrono::high_resolution_clock::now() - wall0).count();
     }

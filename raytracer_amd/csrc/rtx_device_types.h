@@ -26,9 +26,10 @@ struct Node {
 };
 static_assert(sizeof(Node) == 128, "Node must be 128 bytes");
 
-// Hot triangle record: vertex a and the two edges (b - a), (c - a).
-struct Tri { double a[3], e1[3], e2[3]; };
-static_assert(sizeof(Tri) == 72, "Tri must be 72 bytes");
+// Hot triangle record: vertex a and the two edges (b - a), (c - a), plus the original face
+// index; padded to 80 bytes so that records start on 16-byte boundaries (five 16-byte pieces).
+struct Tri { double a[3], e1[3], e2[3]; int32_t face, pad; };
+static_assert(sizeof(Tri) == 80, "Tri must be 80 bytes");
 
 struct Mesh {
     double rmin[3], rmax[3];     // root box (tested before anything else, bvh.cpp:132 on node 0)
@@ -89,7 +90,6 @@ struct Scene {
     const Tri* tris;
     const double* tri_gn;     // 3 per triangle: normalize((b-a) x (c-a))
     const double* tri_vn;     // 9 per triangle (vertex normals of its corners) or null
-    const int32_t* tri_face;  // original face index of each triangle
     const TlasNode* tlas;
     const int32_t* tlas_order;
     // TLAS root (may itself be a leaf)
@@ -102,11 +102,12 @@ struct Frame {
     double e[3], u[3], v[3], q[3];
     double r_minus_l, t_minus_b;
     int32_t width, height;
-    int32_t tile_w, tile_h, tiles_x, tile_first, tile_stride, n_local_pixels;
+    int32_t tile_w, tile_h, tiles_x, tile_first, tile_stride;
+    int32_t n_items0;       // generation-0 work items: selected tiles x 8x8 blocks x 64
 };
 
-// Ray queue (structure of arrays).  kind: 0 = radiance ray, 1 = shadow ray.
-// meta = depth | kind << 8 | (beer_material + 1) << 9
+// Ray queue (structure of arrays).  Radiance rays occupy slots 0, 1, ... and shadow rays
+// slots capacity-1, capacity-2, ...; meta = depth | (beer_material + 1) << 8.
 struct Queue {
     double* ox; double* oy; double* oz;
     double* dx; double* dy; double* dz;
@@ -117,9 +118,30 @@ struct Queue {
     uint32_t capacity;
 };
 
+// Closest-hit records of the radiance rays of one generation (structure of arrays, indexed
+// by queue slot; by work item for generation 0).  code: -1 miss, 0 hit without material,
+// m+1 hit with material m.
+struct HitBuf {
+    double* dist;
+    double* px; double* py; double* pz;
+    double* gx; double* gy; double* gz;     // geometric normal
+    double* sx; double* sy; double* sz;     // shading normal
+    int32_t* code;
+};
+
+// Control block of one generation.  counts packs the number of radiance rays (low half) and
+// shadow rays (high half) so that one 64-bit atomic reserves slots at either end of the
+// queue and observes the other end's fill level at the same instant.
+struct GenCtrl {
+    unsigned head_trace, head_shade;
+    unsigned long long counts;
+    unsigned overflow, pad[3];
+};
+
 struct Counters {
     unsigned long long rays, primary, shadow, secondary;
     unsigned long long node_visits, tri_tests, world_box_tests, object_traversals, tlas_visits;
+    unsigned long long inner_steps, inner_lanes, leaf_steps, leaf_lanes;
 };
 
 }  // namespace rtxdev

@@ -1,16 +1,29 @@
 // HIP kernels of the ray-casting core (gfx950, wave64).
 //
-// One kernel, k_trace, processes one *generation* of rays: generation 0 are the camera
-// rays (generated in-kernel, utils.cpp:134-158), generation g+1 holds every ray spawned
-// while shading generation g (shadow rays, mirror/conductor reflections, dielectric
-// reflection + refraction).  The reference's recursion (utils.cpp:868-1061) is linear in
-// every child colour, so each queued ray carries an RGB weight and adds
-// weight x (its own shaded terms) to its pixel; Beer-Lambert absorption depends on the
-// child's hit distance and is applied when the child resolves.
+// A frame is processed in *generations*: generation 0 are the camera rays (generated
+// in-kernel, utils.cpp:134-158), generation g+1 holds every ray spawned while shading
+// generation g (shadow rays, mirror/conductor reflections, dielectric reflection +
+// refraction).  The reference's recursion (utils.cpp:868-1061) is linear in every child
+// colour, so each queued ray carries an RGB weight and adds weight x (its own shaded terms)
+// to its pixel; Beer-Lambert absorption depends on the child's hit distance and is applied
+// when the child resolves.  Per generation two kernels run:
 //
-// Work distribution is persistent-thread style: every wave repeatedly claims the next 64
-// rays with one atomic add (lane 0) + readfirstlane broadcast, and appends children with a
+//   k_trace  closest-hit query for every queued ray (the dominant kernel).  Shadow rays
+//            finish here (their carried contribution is added iff unoccluded); radiance
+//            rays leave a hit record in HBM.
+//   k_shade  shades the radiance hits and appends the next generation's rays.
+//
+// Work distribution is persistent-thread style: every wave repeatedly claims a batch of
+// rays with one atomic add (lane 0) + readfirstlane broadcast; children are appended with a
 // ballot-compacted reservation (one atomic per wave per child slot), so queues stay dense.
+//
+// Traversal is wave-cooperative.  Each lane walks its own ray through the BVH with its own
+// stack, but the 128-byte node (or 80-byte triangle) records the lanes need are fetched by
+// the whole wave: eight lanes read one record as eight adjacent 16-byte pieces, so one
+// load instruction touches 8 records x 128 contiguous bytes instead of 64 scattered
+// 16-byte pieces, and the record is handed to its owner lane through a per-wave LDS row.
+// Lanes alternate between an inner-node phase and a leaf phase by majority vote
+// (while-while traversal), which keeps each lane's own visit order untouched.
 //
 // All geometry arithmetic is FP64 in the reference's operation order and this file must be
 // compiled with -ffp-contract=off: primary-hit identity has to match the reference bit for
@@ -18,6 +31,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <float.h>
+#include <limits.h>
 #include <math.h>
 #include "rtx_amd.h"
 #include "rtx_device_types.h"
@@ -149,9 +163,40 @@ RTX_DEV bool tri_test(const double* T, V3 o, V3 d, double t_min, double eps, dou
     return false;
 }
 
-struct Tally { unsigned node_visits, tri_tests, world_box, obj_trav, tlas_visits; };
+struct Tally { unsigned node_visits, tri_tests, world_box, obj_trav, tlas_visits;
+               unsigned inner_steps, inner_lanes, leaf_steps, leaf_lanes; };   // wave-step occupancy (lane 0 only)
 
 #define RTX_STACK 64
+#define RTX_ROW_DOUBLES 18          // 144-byte LDS row per lane: 128-byte record + 16 bytes of
+                                    // padding so that 16 lanes' ds_read_b128 hit distinct banks
+
+RTX_DEV unsigned lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+
+// Per-wave context: this wave's 64 LDS rows and the lane number.
+struct Wave { double* rows; unsigned lane; };
+
+// Wave-cooperative gather of one fixed-size record per requesting lane into that lane's LDS
+// row.  `mask` = ballot of the requesting lanes, `index` = record number (valid in requesting
+// lanes), records start at base + index*STRIDE and are NCHUNK*16 bytes long.  Eight lanes
+// serve one owner (owner = 8g + lane/8, piece = lane%8 in round g), so each load instruction
+// reads up to 8 whole records.  Must be executed by every lane of the wave.
+template <int NCHUNK, int STRIDE>
+RTX_DEV void coop_fetch(const Wave& wv, unsigned long long mask, int index, const char* __restrict__ base) {
+    const unsigned sub = wv.lane >> 3, piece = wv.lane & 7u;
+#pragma unroll
+    for (int g = 0; g < 8; g++) {
+        const unsigned gm = (unsigned)(mask >> (8 * g)) & 0xFFu;        // wave-uniform
+        if (gm) {
+            const int owner = 8 * g + (int)sub;
+            const int oidx = __shfl(index, owner);
+            if (((gm >> sub) & 1u) && (int)piece < NCHUNK) {
+                const float4 v = *(const float4*)(base + (size_t)oidx * STRIDE + piece * 16u);
+                *(float4*)((char*)wv.rows + owner * (RTX_ROW_DOUBLES * 8) + piece * 16u) = v;
+            }
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+}
 
 // BLAS traversal with the visit order and the visited set of bvh.cpp:104-185: children are
 // ordered near/far by the sign of dir[splitAxis] (near popped first), a node is entered iff
@@ -159,61 +204,93 @@ struct Tally { unsigned node_visits, tri_tests, world_box, obj_trav, tlas_visits
 // Both children's boxes are evaluated when their parent is visited; the far child is pushed
 // together with its entry distance and re-checked against the (possibly smaller) bound when
 // popped, which is the same predicate the reference evaluates at that moment.
+//
+// Called by the whole wave; `go` marks the lanes that actually traverse (their own mesh,
+// ray and bound).  Returns per lane whether a closer triangle was found.
 template <bool COUNT>
-RTX_DEV bool blas_traverse(const Scene& S, const Mesh& m, V3 o, V3 d, double& t_min, int& best_tri,
-                           double& best_beta, double& best_gamma, Tally& tl) {
+RTX_DEV bool blas_traverse(const Scene& S, const Wave& wv, bool go, int mesh_index, V3 o, V3 d, double& t_min,
+                           int& best_tri, double& best_beta, double& best_gamma, Tally& tl) {
     const Slab sl = make_slab(o, d);
-    double enter;
-    if (!box_enter(m.rmin, m.rmax, sl, enter) || !(t_min >= enter)) return false;
-    int cur_ref = m.root_ref, cur_cnt = m.root_count;
+    bool alive = false;
+    int cur_ref = 0, cur_cnt = 0;
+    if (go) {
+        const Mesh& m = S.meshes[mesh_index];
+        double enter;
+        alive = box_enter(m.rmin, m.rmax, sl, enter) && (t_min >= enter);
+        cur_ref = m.root_ref; cur_cnt = m.root_count;
+    }
     int stk_ref[RTX_STACK], stk_cnt[RTX_STACK];
     double stk_t[RTX_STACK];
     int sp = 0;
     bool found = false;
-    const double dax[3] = {d.x, d.y, d.z};
+    const double* row = wv.rows + wv.lane * RTX_ROW_DOUBLES;
+
     while (true) {
+        const bool at_inner = alive && cur_cnt == 0;
+        const bool at_leaf = alive && cur_cnt > 0;
+        const unsigned long long m_inner = __ballot(at_inner);
+        const unsigned long long m_leaf = __ballot(at_leaf);
+        if ((m_inner | m_leaf) == 0ull) break;
         bool need_pop = false;
-        if (cur_cnt > 0) {
-            for (int i = 0; i < cur_cnt; i++) {
-                const int ti = cur_ref + i;
-                if (COUNT) tl.tri_tests++;
-                if (S.cull) {
-                    const double* g = S.tri_gn + 3 * (size_t)ti;
-                    if (d.x * g[0] + d.y * g[1] + d.z * g[2] > 0.0) continue;
-                }
-                double t, b, g2;
-                if (tri_test((const double*)(S.tris + ti), o, d, t_min, S.isect_eps, t, b, g2)) {
-                    t_min = t; best_tri = ti; best_beta = b; best_gamma = g2; found = true;
+        // Phase choice by majority: a leaf step costs several inner steps, so leaves wait until
+        // they clearly outnumber the lanes still descending.
+        if (m_inner != 0ull && 2 * __popcll(m_inner) >= __popcll(m_leaf)) {
+            if (COUNT && wv.lane == 0) { tl.inner_steps++; tl.inner_lanes += (unsigned)__popcll(m_inner); }
+            coop_fetch<8, 128>(wv, m_inner, cur_ref, (const char*)S.nodes);
+            if (at_inner) {
+                if (COUNT) tl.node_visits++;
+                const int* ri = (const int*)(row + 12);
+                double el, er;
+                const bool okl = box_enter(row + 0, row + 3, sl, el) && (t_min >= el);
+                const bool okr = box_enter(row + 6, row + 9, sl, er) && (t_min >= er);
+                const int lref = ri[0], lcnt = ri[1], rref = ri[2], rcnt = ri[3], axis = ri[4];
+                const double da = axis == 0 ? d.x : (axis == 1 ? d.y : d.z);
+                const bool left_near = da >= 0.0;
+                const int nref = left_near ? lref : rref, ncnt = left_near ? lcnt : rcnt;
+                const int fref = left_near ? rref : lref, fcnt = left_near ? rcnt : lcnt;
+                const bool okn = left_near ? okl : okr, okf = left_near ? okr : okl;
+                const double ef = left_near ? er : el;
+                if (okn) {
+                    if (okf && sp < RTX_STACK) { stk_ref[sp] = fref; stk_cnt[sp] = fcnt; stk_t[sp] = ef; sp++; }
+                    cur_ref = nref; cur_cnt = ncnt;
+                } else if (okf) {
+                    cur_ref = fref; cur_cnt = fcnt;
+                } else {
+                    need_pop = true;
                 }
             }
-            need_pop = true;
+            __builtin_amdgcn_wave_barrier();
         } else {
-            const Node& n = S.nodes[cur_ref];
-            if (COUNT) tl.node_visits++;
-            double el, er;
-            bool okl = box_enter(n.lmin, n.lmax, sl, el) && (t_min >= el);
-            bool okr = box_enter(n.rmin, n.rmax, sl, er) && (t_min >= er);
-            const bool left_near = dax[n.axis] >= 0.0;
-            int nref = left_near ? n.lref : n.rref, ncnt = left_near ? n.lcount : n.rcount;
-            int fref = left_near ? n.rref : n.lref, fcnt = left_near ? n.rcount : n.lcount;
-            bool okn = left_near ? okl : okr, okf = left_near ? okr : okl;
-            double ef = left_near ? er : el;
-            if (okn) {
-                if (okf && sp < RTX_STACK) { stk_ref[sp] = fref; stk_cnt[sp] = fcnt; stk_t[sp] = ef; sp++; }
-                cur_ref = nref; cur_cnt = ncnt;
-            } else if (okf) {
-                cur_ref = fref; cur_cnt = fcnt;
-            } else {
-                need_pop = true;
+            // leaf phase: triangle k of every leaf lane, in leaf order
+            for (int k = 0;; k++) {
+                const bool want = at_leaf && k < cur_cnt;
+                const unsigned long long mk_ = __ballot(want);
+                if (mk_ == 0ull) break;
+                if (COUNT && wv.lane == 0) { tl.leaf_steps++; tl.leaf_lanes += (unsigned)__popcll(mk_); }
+                coop_fetch<5, 80>(wv, mk_, cur_ref + k, (const char*)S.tris);
+                if (want) {
+                    const int ti = cur_ref + k;
+                    if (COUNT) tl.tri_tests++;
+                    bool culled = false;
+                    if (S.cull) {
+                        const double* g = S.tri_gn + 3 * (size_t)ti;
+                        culled = d.x * g[0] + d.y * g[1] + d.z * g[2] > 0.0;
+                    }
+                    double t, b, g2;
+                    if (!culled && tri_test(row, o, d, t_min, S.isect_eps, t, b, g2)) {
+                        t_min = t; best_tri = ti; best_beta = b; best_gamma = g2; found = true;
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
             }
+            need_pop = at_leaf;
         }
         if (need_pop) {
-            bool got = false;
+            alive = false;
             while (sp > 0) {
                 --sp;
-                if (t_min >= stk_t[sp]) { cur_ref = stk_ref[sp]; cur_cnt = stk_cnt[sp]; got = true; break; }
+                if (t_min >= stk_t[sp]) { cur_ref = stk_ref[sp]; cur_cnt = stk_cnt[sp]; alive = true; break; }
             }
-            if (!got) break;
         }
     }
     return found;
@@ -222,8 +299,8 @@ RTX_DEV bool blas_traverse(const Scene& S, const Mesh& m, V3 o, V3 d, double& t_
 // Fields a successful triangle test writes (utils.cpp:370-381) + kind (bvh.cpp:162).
 RTX_DEV void write_tri_hit(const Scene& S, Rec& r, int tri, double t, double beta, double gamma,
                            int material, int container) {
-    const double* T = (const double*)(S.tris + tri);
-    V3 a = mk(T[0], T[1], T[2]), e1 = mk(T[3], T[4], T[5]), e2 = mk(T[6], T[7], T[8]);
+    const Tri& T = S.tris[tri];
+    V3 a = ld3(T.a), e1 = ld3(T.e1), e2 = ld3(T.e2);
     r.hit = 1;
     r.dist = t;
     r.point = vadd(vadd(a, sscale(beta, e1)), sscale(gamma, e2));
@@ -232,38 +309,43 @@ RTX_DEV void write_tri_hit(const Scene& S, Rec& r, int tri, double t, double bet
     r.beta = beta; r.gamma = gamma;
     r.mat = material;
     r.container = container;
-    r.face = S.tri_face[tri];
+    r.face = T.face;
     r.tri = tri;
     r.kind = RTX_KIND_MESH;
 }
 
-// rayHitsMesh (utils.cpp:396-669) for mesh `mi` under transform `xfi` (-1: none).
+// rayHitsMesh (utils.cpp:396-669) for mesh `mi` under transform `xfi` (-1: none).  Called by
+// the whole wave; lanes with act == false only help with the cooperative fetches.
 template <bool COUNT>
-RTX_DEV bool mesh_hit(const Scene& S, V3 o, V3 d, int mi, int xfi, int material, double& t_min, Rec& r,
-                      Tally& tl) {
-    const Mesh& m = S.meshes[mi];
-    if (m.n_faces <= 0) return false;
+RTX_DEV bool mesh_hit(const Scene& S, const Wave& wv, bool act, V3 o, V3 d, int mi, int xfi, int material,
+                      double& t_min, Rec& r, Tally& tl) {
+    bool go = act;
+    if (go && S.meshes[mi].n_faces <= 0) go = false;
+    V3 ro = o, rd = d;
+    const double original_t_min = t_min;
+    if (go && xfi >= 0) {
+        const Xform& xf = S.xforms[xfi];
+        if (xf.has_bounds) {
+            if (COUNT) tl.world_box++;
+            const Slab sl = make_slab(o, d);
+            double enter;
+            if (!box_enter(xf.bmin, xf.bmax, sl, enter) || !(t_min >= enter)) go = false;
+        }
+        if (go) {
+            if (COUNT) tl.obj_trav++;
+            ro = xf_point(xf.inv, o);
+            rd = normalize_f32(xf_dir(xf.inv, d));
+        }
+    }
     int tri = -1;
     double beta = 0, gamma = 0;
-    if (xfi < 0) {
-        if (!blas_traverse<COUNT>(S, m, o, d, t_min, tri, beta, gamma, tl)) return false;
-        write_tri_hit(S, r, tri, t_min, beta, gamma, material, mi);
-        return true;
-    }
-    const Xform& xf = S.xforms[xfi];
-    if (xf.has_bounds) {
-        if (COUNT) tl.world_box++;
-        const Slab sl = make_slab(o, d);
-        double enter;
-        if (!box_enter(xf.bmin, xf.bmax, sl, enter) || !(t_min >= enter)) return false;
-    }
-    const double original_t_min = t_min;
-    if (COUNT) tl.obj_trav++;
-    V3 oo = xf_point(xf.inv, o);
-    V3 od = normalize_f32(xf_dir(xf.inv, d));
-    if (!blas_traverse<COUNT>(S, m, oo, od, t_min, tri, beta, gamma, tl)) return false;
+    const bool found = blas_traverse<COUNT>(S, wv, go, mi, ro, rd, t_min, tri, beta, gamma, tl);
+    if (!(go && found)) return false;
     write_tri_hit(S, r, tri, t_min, beta, gamma, material, mi);
+    if (xfi < 0) return true;
 
+    const Xform& xf = S.xforms[xfi];
+    const Mesh& m = S.meshes[mi];
     V3 wp = xf_point(xf.m, r.point);
     double dx = wp.x - o.x, dy = wp.y - o.y, dz = wp.z - o.z;
     double wd = (double)sqrtf((float)(dx * dx + dy * dy + dz * dz));
@@ -422,22 +504,66 @@ RTX_DEV void free_tri_hit(const Scene& S, V3 ro, V3 rd, int index, double& t_min
 
 #define RTX_CAND 8
 
-// Closest-hit query with the reference's object order and state machine (utils.cpp:671-865).
+// Collect, for one ray, the RTX_CAND smallest instance indices > last whose world box the ray
+// meets within the bound (TLAS walk; per-lane, no cross-lane work).
 template <bool COUNT>
-RTX_DEV void intersect(const Scene& S, V3 o, V3 d, Rec& r, Tally& tl) {
+RTX_DEV void tlas_collect(const Scene& S, const Slab& sl, double t_min, int last, int (&buf)[RTX_CAND], Tally& tl) {
+    double enter;
+    if (!(S.tl_max_idx > last && box_enter(S.tl_min, S.tl_max, sl, enter) && (t_min >= enter))) return;
+    int stk_ref[RTX_STACK], stk_cnt[RTX_STACK];
+    int sp = 1;
+    stk_ref[0] = S.tl_ref; stk_cnt[0] = S.tl_count;
+    while (sp > 0) {
+        --sp;
+        const int ref = stk_ref[sp], cnt = stk_cnt[sp];
+        if (cnt > 0) {
+            for (int k = 0; k < cnt; k++) {
+                const int idx = S.tlas_order[ref + k];
+                if (idx > last && idx < buf[RTX_CAND - 1]) {
+                    int x = idx;                 // sorted insert, largest falls off
+#pragma unroll
+                    for (int q = 0; q < RTX_CAND; q++) {
+                        const int lo = min(buf[q], x), hi = max(buf[q], x);
+                        buf[q] = lo; x = hi;
+                    }
+                }
+            }
+        } else {
+            const TlasNode& n = S.tlas[ref];
+            if (COUNT) tl.tlas_visits++;
+            double e;
+            if (n.lmax_idx > last && n.lmin_idx < buf[RTX_CAND - 1] && box_enter(n.lmin, n.lmax, sl, e) &&
+                (t_min >= e) && sp < RTX_STACK) {
+                stk_ref[sp] = n.lref; stk_cnt[sp] = n.lcount; sp++;
+            }
+            if (n.rmax_idx > last && n.rmin_idx < buf[RTX_CAND - 1] && box_enter(n.rmin, n.rmax, sl, e) &&
+                (t_min >= e) && sp < RTX_STACK) {
+                stk_ref[sp] = n.rref; stk_cnt[sp] = n.rcount; sp++;
+            }
+        }
+    }
+}
+
+// Closest-hit query with the reference's object order and state machine (utils.cpp:671-865).
+// Executed by the whole wave; `active` marks the lanes that carry a ray.
+template <bool COUNT>
+RTX_DEV void intersect(const Scene& S, const Wave& wv, bool active, V3 o, V3 d, Rec& r, Tally& tl) {
     double t_min = DBL_MAX;
     r.hit = 0; r.dist = 0.0; r.beta = 0.0; r.gamma = 0.0;
     r.point = mk(0, 0, 0); r.gn = mk(0, 0, 0); r.sn = mk(0, 0, 0);
     r.kind = RTX_KIND_NONE; r.container = -1; r.face = -1; r.tri = -1; r.mat = -1; r.src = -1;
     bool hit = false;
 
-    for (int i = 0; i < S.n_planes; i++) hit = plane_hit(S, o, d, i, t_min, r) || hit;
-    for (int i = 0; i < S.n_ftris; i++) free_tri_hit<COUNT>(S, o, d, i, t_min, r, hit, tl);
-    for (int i = 0; i < S.n_meshes; i++) {
-        const Mesh& m = S.meshes[i];
-        if (mesh_hit<COUNT>(S, o, d, i, m.xform, m.material, t_min, r, tl)) { hit = true; r.src = i; }
+    if (active) {
+        for (int i = 0; i < S.n_planes; i++) hit = plane_hit(S, o, d, i, t_min, r) || hit;
+        for (int i = 0; i < S.n_ftris; i++) free_tri_hit<COUNT>(S, o, d, i, t_min, r, hit, tl);
     }
-    for (int i = 0; i < S.n_spheres; i++) hit = sphere_hit(S, o, d, i, t_min, r) || hit;
+    for (int i = 0; i < S.n_meshes; i++) {                      // wave-uniform loop
+        const Mesh& m = S.meshes[i];
+        if (mesh_hit<COUNT>(S, wv, active, o, d, i, m.xform, m.material, t_min, r, tl)) { hit = true; r.src = i; }
+    }
+    if (active)
+        for (int i = 0; i < S.n_spheres; i++) hit = sphere_hit(S, o, d, i, t_min, r) || hit;
 
     // Instances (utils.cpp:756-790).  The TLAS only selects candidates -- instances whose
     // world box the ray meets within the current bound; a box missed now stays missed
@@ -446,66 +572,37 @@ RTX_DEV void intersect(const Scene& S, V3 o, V3 d, Rec& r, Tally& tl) {
     if (S.n_insts > 0) {
         const Slab sl = make_slab(o, d);
         int last = -1;
-        while (true) {
+        bool more = active;
+        while (__ballot(more) != 0ull) {
             int buf[RTX_CAND];
 #pragma unroll
             for (int k = 0; k < RTX_CAND; k++) buf[k] = INT_MAX;
-            {
-                double enter;
-                bool ok = S.tl_max_idx > last && box_enter(S.tl_min, S.tl_max, sl, enter) && (t_min >= enter);
-                int stk_ref[RTX_STACK], stk_cnt[RTX_STACK];
-                int sp = 0;
-                if (ok) { stk_ref[0] = S.tl_ref; stk_cnt[0] = S.tl_count; sp = 1; }
-                while (sp > 0) {
-                    --sp;
-                    int ref = stk_ref[sp], cnt = stk_cnt[sp];
-                    if (cnt > 0) {
-                        for (int k = 0; k < cnt; k++) {
-                            int idx = S.tlas_order[ref + k];
-                            if (idx > last && idx < buf[RTX_CAND - 1]) {
-                                int x = idx;                 // sorted insert, largest falls off
-#pragma unroll
-                                for (int q = 0; q < RTX_CAND; q++) {
-                                    int lo = min(buf[q], x), hi = max(buf[q], x);
-                                    buf[q] = lo; x = hi;
-                                }
-                            }
-                        }
-                    } else {
-                        const TlasNode& n = S.tlas[ref];
-                        if (COUNT) tl.tlas_visits++;
-                        double e;
-                        if (n.lmax_idx > last && n.lmin_idx < buf[RTX_CAND - 1] &&
-                            box_enter(n.lmin, n.lmax, sl, e) && (t_min >= e) && sp < RTX_STACK) {
-                            stk_ref[sp] = n.lref; stk_cnt[sp] = n.lcount; sp++;
-                        }
-                        if (n.rmax_idx > last && n.rmin_idx < buf[RTX_CAND - 1] &&
-                            box_enter(n.rmin, n.rmax, sl, e) && (t_min >= e) && sp < RTX_STACK) {
-                            stk_ref[sp] = n.rref; stk_cnt[sp] = n.rcount; sp++;
-                        }
-                    }
-                }
-            }
-            if (buf[0] == INT_MAX) break;
+            if (more) tlas_collect<COUNT>(S, sl, t_min, last, buf, tl);
             const bool full = buf[RTX_CAND - 1] != INT_MAX;
-            while (buf[0] != INT_MAX) {
+            bool have = more && buf[0] != INT_MAX;
+            while (__ballot(have) != 0ull) {
                 const int idx = buf[0];
 #pragma unroll
                 for (int q = 0; q + 1 < RTX_CAND; q++) buf[q] = buf[q + 1];
                 buf[RTX_CAND - 1] = INT_MAX;
-                last = idx;
-                const Inst& in = S.insts[idx];
-                if (mesh_hit<COUNT>(S, o, d, in.base_mesh, in.xform, in.material, t_min, r, tl)) {
+                int base_mesh = 0, xform = -1, material = -1;
+                if (have) {
+                    last = idx;
+                    const Inst& in = S.insts[idx];
+                    base_mesh = in.base_mesh; xform = in.xform; material = in.material;
+                }
+                if (mesh_hit<COUNT>(S, wv, have, o, d, base_mesh, xform, material, t_min, r, tl)) {
                     hit = true; r.src = S.n_meshes + idx;
                 }
+                have = have && buf[0] != INT_MAX;
             }
-            if (!full) break;
+            more = more && full;
         }
     }
 
-    if (!hit) { r.hit = 0; return; }
-    // utils.cpp:807-853.  Note r.hit may be left 1 by a rejected transformed hit only when
-    // an earlier object already hit, so `hit` and r.hit agree here.
+    if (!(active && hit)) { r.hit = 0; return; }
+    // utils.cpp:807-853.  r.hit can be left set by a rejected transformed hit only when an
+    // earlier object already hit, so `hit` and r.hit agree here.
     const double u = r.beta, v = r.gamma, w = 1.0 - u - v;
     r.gn = normalize(r.gn);
     r.sn = normalize(r.sn);
@@ -548,29 +645,35 @@ RTX_DEV double fresnel_dielectric(double cosTheta, double n1, double n2) {
     return 0.5 * (rPerp * rPerp + rPara * rPara);
 }
 
-RTX_DEV unsigned lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+#define RTX_META(depth, beer) ((unsigned)(depth) | ((unsigned)((beer) + 1) << 8))
 
-// Append one ray per requesting lane to the output queue: ballot, one reservation per wave,
-// dense coalesced stores.  Must be reached by every lane of the wave.
-RTX_DEV void emit(const Queue& q, unsigned* tail, unsigned* overflow, bool want, V3 o, V3 d, V3 w,
-                  double aux, unsigned pixel, unsigned meta) {
+// Append one ray per requesting lane: ballot, one reservation per wave, dense stores.
+// Radiance rays go to slot k, shadow rays to slot capacity-1-k.  Must be reached by every
+// lane of the wave.
+RTX_DEV void emit(const Queue& q, GenCtrl* next, bool shadow, bool want, V3 o, V3 d, V3 w, double aux,
+                  unsigned pixel, unsigned meta) {
     const unsigned long long mask = __ballot(want);
-    if (mask == 0) return;
+    if (mask == 0ull) return;
     const unsigned lane = lane_id();
     const int leader = __ffsll((long long)mask) - 1;
-    unsigned base = 0;
-    if ((int)lane == leader) base = atomicAdd(tail, (unsigned)__popcll(mask));
-    base = __shfl(base, leader);
+    const unsigned n = (unsigned)__popcll(mask);
+    unsigned long long old = 0;
+    if ((int)lane == leader) old = atomicAdd(&next->counts, shadow ? ((unsigned long long)n << 32) : (unsigned long long)n);
+    old = __shfl(old, leader);
+    const unsigned base = shadow ? (unsigned)(old >> 32) : (unsigned)old;
+    const unsigned other = shadow ? (unsigned)old : (unsigned)(old >> 32);
+    // Reservations at both ends are totally ordered by the single atomic word, so
+    // base + n + other <= capacity means these slots are not, and will never be, claimed from
+    // the other end.  Otherwise flag the overflow (the frame is redone with larger queues)
+    // and drop the rays.
+    if ((unsigned long long)base + n + other > q.capacity) { if ((int)lane == leader) next->overflow = 1u; return; }
     if (want) {
-        const unsigned idx = base + (unsigned)__popcll(mask & ((1ull << lane) - 1ull));
-        if (idx < q.capacity) {
-            q.ox[idx] = o.x; q.oy[idx] = o.y; q.oz[idx] = o.z;
-            q.dx[idx] = d.x; q.dy[idx] = d.y; q.dz[idx] = d.z;
-            q.wx[idx] = w.x; q.wy[idx] = w.y; q.wz[idx] = w.z;
-            q.aux[idx] = aux; q.pixel[idx] = pixel; q.meta[idx] = meta;
-        } else {
-            *overflow = 1u;
-        }
+        const unsigned k = base + (unsigned)__popcll(mask & ((1ull << lane) - 1ull));
+        const unsigned idx = shadow ? q.capacity - 1u - k : k;
+        q.ox[idx] = o.x; q.oy[idx] = o.y; q.oz[idx] = o.z;
+        q.dx[idx] = d.x; q.dy[idx] = d.y; q.dz[idx] = d.z;
+        q.wx[idx] = w.x; q.wy[idx] = w.y; q.wz[idx] = w.z;
+        q.aux[idx] = aux; q.pixel[idx] = pixel; q.meta[idx] = meta;
     }
 }
 
@@ -580,20 +683,55 @@ RTX_DEV void add_color(double* accum, unsigned pixel, V3 c) {
     if (c.z != 0.0) atomicAdd(accum + 3 * (size_t)pixel + 2, c.z);
 }
 
-// Control block of one generation.
-struct GenCtrl { unsigned head, count, overflow, pad; };
+// Generation-0 work item -> pixel.  64 consecutive items form an 8x8 pixel block of one tile,
+// so the rays of a wave are coherent.  Returns false for padding items outside the image.
+RTX_DEV bool primary_pixel(const Frame& F, unsigned item, int& px, int& py, unsigned& local_pixel) {
+    const int bpt_x = (F.tile_w + 7) >> 3, bpt_y = (F.tile_h + 7) >> 3;
+    const unsigned blk = item >> 6, l = item & 63u;
+    const unsigned bpt = (unsigned)(bpt_x * bpt_y);
+    const unsigned k = blk / bpt, b = blk % bpt;
+    const int tx = (int)(b % (unsigned)bpt_x) * 8 + (int)(l & 7u);
+    const int ty = (int)(b / (unsigned)bpt_x) * 8 + (int)(l >> 3);
+    const unsigned tile = (unsigned)F.tile_first + k * (unsigned)F.tile_stride;
+    px = (int)(tile % (unsigned)F.tiles_x) * F.tile_w + tx;
+    py = (int)(tile / (unsigned)F.tiles_x) * F.tile_h + ty;
+    local_pixel = k * (unsigned)(F.tile_w * F.tile_h) + (unsigned)(ty * F.tile_w + tx);
+    return tx < F.tile_w && ty < F.tile_h && px < F.width && py < F.height;
+}
 
-#define RTX_META(depth, kind, beer) ((unsigned)(depth) | ((unsigned)(kind) << 8) | ((unsigned)((beer) + 1) << 9))
+// utils.cpp:142-156 with the camera basis precomputed per frame.
+RTX_DEV V3 primary_direction(const Frame& F, int px, int py) {
+    double s_u = (px + 0.5) * F.r_minus_l / F.width;
+    double s_v = (py + 0.5) * F.t_minus_b / F.height;
+    V3 e = ld3(F.e), u = ld3(F.u), v = ld3(F.v), q = ld3(F.q);
+    V3 s = vsub(vadd(q, vscale(u, s_u)), vscale(v, s_v));
+    return normalize(vsub(s, e));
+}
+
+// Queue slot of trace work item w: radiance rays first, then shadow rays (stored from the back).
+RTX_DEV unsigned queue_slot(unsigned w, unsigned n_radiance, unsigned capacity) {
+    return w < n_radiance ? w : capacity - 1u - (w - n_radiance);
+}
 
 template <bool COUNT>
 __global__ void __launch_bounds__(256)
-k_trace(const Scene S, const Frame F, const Queue qin, const Queue qout, GenCtrl* ctrl, const int gen,
+k_trace(const Scene S, const Frame F, const Queue qin, const HitBuf hb, GenCtrl* ctrl, const int gen,
         double* __restrict__ accum, rtx_hit_id* __restrict__ aov, Counters* __restrict__ counters) {
-    const unsigned lane = lane_id();
+    __shared__ __attribute__((aligned(16))) double lds_rows[4][64 * RTX_ROW_DOUBLES];
+    Wave wv;
+    wv.lane = lane_id();
+    wv.rows = &lds_rows[threadIdx.x >> 6][0];
+    const unsigned lane = wv.lane;
     GenCtrl* me = ctrl + gen;
-    GenCtrl* next = ctrl + gen + 1;
-    const unsigned n_in = gen == 0 ? (unsigned)F.n_local_pixels : min(me->count, qin.capacity);
-    Tally tl = {0, 0, 0, 0, 0};
+    unsigned n_rad = 0, n_in = 0;
+    if (gen == 0) { n_rad = (unsigned)F.n_items0; n_in = n_rad; }
+    else {
+        // after an overflow the counters may exceed what was stored; clamp (the frame is redone)
+        const unsigned long long c = me->counts;
+        n_rad = min((unsigned)c, qin.capacity);
+        n_in = n_rad + min((unsigned)(c >> 32), qin.capacity - n_rad);
+    }
+    Tally tl = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     unsigned n_rays = 0, n_primary = 0, n_shadow = 0, n_secondary = 0;
 
     // Rays claimed per wave and fetch: 64 when the generation can fill the whole grid,
@@ -608,55 +746,32 @@ k_trace(const Scene S, const Frame F, const Queue qin, const Queue qout, GenCtrl
 
     while (true) {
         unsigned base = 0;
-        if (lane == 0) base = atomicAdd(&me->head, batch);
+        if (lane == 0) base = atomicAdd(&me->head_trace, batch);
         base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
         if (base >= n_in) break;
-        const unsigned idx = base + lane;
-        bool active = lane < batch && idx < n_in;
+        const unsigned item = base + lane;
+        bool active = lane < batch && item < n_in;
 
-        V3 o = mk(0, 0, 0), d = mk(0, 0, 1), W = mk(1, 1, 1);
-        double aux = 0.0;
-        unsigned pixel = 0, depth = 0, kind = 0;
-        int beer = -1, px = 0, py = 0;
+        V3 o = mk(0, 0, 0), d = mk(0, 0, 1);
+        unsigned slot = item, pixel = 0;
+        int px = 0, py = 0;
+        bool is_shadow = false;
         if (gen == 0) {
-            // 64 consecutive work items form an 8x8 pixel block of one tile: coherent rays.
-            const int bpt_x = (F.tile_w + 7) >> 3, bpt_y = (F.tile_h + 7) >> 3;
-            const unsigned blk = idx >> 6;
-            const unsigned bpt = (unsigned)(bpt_x * bpt_y);
-            const unsigned k = blk / bpt, b = blk % bpt;
-            const int tx = (int)(b % (unsigned)bpt_x) * 8 + (int)(lane & 7);
-            const int ty = (int)(b / (unsigned)bpt_x) * 8 + (int)(lane >> 3);
-            const unsigned tile = (unsigned)F.tile_first + k * (unsigned)F.tile_stride;
-            px = (int)(tile % (unsigned)F.tiles_x) * F.tile_w + tx;
-            py = (int)(tile / (unsigned)F.tiles_x) * F.tile_h + ty;
-            active = active && tx < F.tile_w && ty < F.tile_h && px < F.width && py < F.height;
-            pixel = k * (unsigned)(F.tile_w * F.tile_h) + (unsigned)(ty * F.tile_w + tx);
-            if (active) {                                           // utils.cpp:142-156
-                double s_u = (px + 0.5) * F.r_minus_l / F.width;
-                double s_v = (py + 0.5) * F.t_minus_b / F.height;
-                V3 e = ld3(F.e), u = ld3(F.u), v = ld3(F.v), q = ld3(F.q);
-                V3 s = vsub(vadd(q, vscale(u, s_u)), vscale(v, s_v));
-                o = e;
-                d = normalize(vsub(s, e));
-            }
+            active = primary_pixel(F, item, px, py, pixel) && active;
+            if (active) { o = ld3(F.e); d = primary_direction(F, px, py); }
         } else if (active) {
-            o = mk(qin.ox[idx], qin.oy[idx], qin.oz[idx]);
-            d = mk(qin.dx[idx], qin.dy[idx], qin.dz[idx]);
-            W = mk(qin.wx[idx], qin.wy[idx], qin.wz[idx]);
-            aux = qin.aux[idx];
-            pixel = qin.pixel[idx];
-            const unsigned meta = qin.meta[idx];
-            depth = meta & 0xFFu; kind = (meta >> 8) & 1u; beer = (int)(meta >> 9) - 1;
+            is_shadow = item >= n_rad;
+            slot = queue_slot(item, n_rad, qin.capacity);
+            o = mk(qin.ox[slot], qin.oy[slot], qin.oz[slot]);
+            d = mk(qin.dx[slot], qin.dy[slot], qin.dz[slot]);
         }
 
         Rec r;
-        r.hit = 0; r.mat = -1;
-        if (active) {
-            intersect<COUNT>(S, o, d, r, tl);
-            if (COUNT) { n_rays++; if (gen == 0) n_primary++; else if (kind) n_shadow++; else n_secondary++; }
-        }
+        intersect<COUNT>(S, wv, active, o, d, r, tl);
+        if (COUNT && active) { n_rays++; if (gen == 0) n_primary++; else if (is_shadow) n_shadow++; else n_secondary++; }
+        if (!active) continue;
 
-        if (gen == 0 && aov != nullptr && active) {
+        if (gen == 0 && aov != nullptr) {
             rtx_hit_id h;
             h.kind = r.hit ? r.kind : 0;
             h.container = r.hit ? r.container : -1;
@@ -665,22 +780,85 @@ k_trace(const Scene S, const Frame F, const Queue qin, const Queue qout, GenCtrl
             h.distance = r.hit ? r.dist : 0.0;
             aov[(size_t)py * F.width + px] = h;
         }
+        if (is_shadow) {                                             // utils.cpp:1083
+            if (!(r.hit && r.dist < qin.aux[slot]))
+                add_color(accum, qin.pixel[slot], mk(qin.wx[slot], qin.wy[slot], qin.wz[slot]));
+        } else {
+            hb.code[slot] = r.hit ? r.mat + 1 : -1;
+            if (r.hit) {
+                hb.dist[slot] = r.dist;
+                hb.px[slot] = r.point.x; hb.py[slot] = r.point.y; hb.pz[slot] = r.point.z;
+                hb.gx[slot] = r.gn.x; hb.gy[slot] = r.gn.y; hb.gz[slot] = r.gn.z;
+                hb.sx[slot] = r.sn.x; hb.sy[slot] = r.sn.y; hb.sz[slot] = r.sn.z;
+            }
+        }
+    }
 
-        // ---- shading (utils.cpp:868-1061) ------------------------------------------------
+    if (COUNT && counters) {
+        unsigned long long v[13] = {n_rays, n_primary, n_shadow, n_secondary, tl.node_visits, tl.tri_tests,
+                                    tl.world_box, tl.obj_trav, tl.tlas_visits, tl.inner_steps, tl.inner_lanes,
+                                    tl.leaf_steps, tl.leaf_lanes};
+#pragma unroll
+        for (int k = 0; k < 13; k++) {
+            unsigned long long x = v[k];
+            for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off);
+            if (lane == 0 && x) atomicAdd(((unsigned long long*)counters) + k, x);
+        }
+    }
+}
+
+// Shading of the radiance hits of one generation (utils.cpp:868-1061) and emission of the
+// next generation's rays.
+__global__ void __launch_bounds__(256)
+k_shade(const Scene S, const Frame F, const Queue qin, const Queue qout, const HitBuf hb, GenCtrl* ctrl,
+        const int gen, double* __restrict__ accum) {
+    const unsigned lane = lane_id();
+    GenCtrl* me = ctrl + gen;
+    GenCtrl* next = ctrl + gen + 1;
+    const unsigned n_in = gen == 0 ? (unsigned)F.n_items0 : min((unsigned)me->counts, qin.capacity);
+
+    while (true) {
+        unsigned base = 0;
+        if (lane == 0) base = atomicAdd(&me->head_shade, 64u);
+        base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
+        if (base >= n_in) break;
+        const unsigned slot = base + lane;
+        bool active = slot < n_in;
+
+        V3 d = mk(0, 0, 1), W = mk(1, 1, 1);
+        unsigned pixel = 0, depth = 0;
+        int beer = -1;
+        if (gen == 0) {
+            int px, py;
+            active = primary_pixel(F, slot, px, py, pixel) && active;
+            if (active) d = primary_direction(F, px, py);
+        } else if (active) {
+            d = mk(qin.dx[slot], qin.dy[slot], qin.dz[slot]);
+            W = mk(qin.wx[slot], qin.wy[slot], qin.wz[slot]);
+            pixel = qin.pixel[slot];
+            const unsigned meta = qin.meta[slot];
+            depth = meta & 0xFFu; beer = (int)(meta >> 8) - 1;
+        }
+
         bool shade = false;
+        int mat = -1;
+        V3 P = mk(0, 0, 0), gn = mk(0, 0, 1), sn = mk(0, 0, 1);
         if (active) {
-            if (kind == 1) {                                         // shadow ray, utils.cpp:1083
-                if (!(r.hit && r.dist < aux)) add_color(accum, pixel, W);
+            const int code = hb.code[slot];
+            if (code < 0) {
+                if (depth == 0) add_color(accum, pixel, vmul(W, ld3(S.bg)));      // utils.cpp:1055-1058
             } else {
-                if (beer >= 0 && r.hit) {                            // utils.cpp:975-984
+                if (beer >= 0) {                                                     // utils.cpp:975-984
                     const Material& pm = S.materials[beer];
-                    V3 ab = vscale(ld3(pm.sigma), r.dist);
+                    V3 ab = vscale(ld3(pm.sigma), hb.dist[slot]);
                     W = vmul(W, mk(exp(-ab.x), exp(-ab.y), exp(-ab.z)));
                 }
-                if (!r.hit) {
-                    if (depth == 0) add_color(accum, pixel, vmul(W, ld3(S.bg)));   // utils.cpp:1055-1058
-                } else if (r.mat >= 0) {
+                mat = code - 1;
+                if (mat >= 0) {
                     shade = true;
+                    P = mk(hb.px[slot], hb.py[slot], hb.pz[slot]);
+                    gn = mk(hb.gx[slot], hb.gy[slot], hb.gz[slot]);
+                    sn = mk(hb.sx[slot], hb.sy[slot], hb.sz[slot]);
                 }
             }
         }
@@ -691,14 +869,14 @@ k_trace(const Scene S, const Frame F, const Queue qin, const Queue qout, GenCtrl
         bool plain = false;
         V3 lobe_a = mk(0, 0, 0), lobe_s = mk(0, 0, 0);      // diffuse / specular colour of the light loop
         bool c0 = false, c1 = false;
-        V3 c0o = o, c0d = d, c0w = W, c1o = o, c1d = d, c1w = W;
+        V3 c0o = P, c0d = d, c0w = W, c1o = P, c1d = d, c1w = W;
         int c1beer = -1;
         double phong = 0.0;
         if (shade) {
-            const Material& m = S.materials[r.mat];
+            const Material& m = S.materials[mat];
             mtype = m.type;
             phong = m.phong;
-            normal = normalize(r.sn);
+            normal = normalize(sn);
             add_color(accum, pixel, vmul(W, vmul(ld3(m.ambient), ld3(S.ambient))));   // utils.cpp:880
             const bool deeper = (int)depth + 1 <= S.max_depth;
             if (mtype == RTX_MAT_CONDUCTOR) {                        // utils.cpp:885-930
@@ -710,7 +888,7 @@ k_trace(const Scene S, const Frame F, const Queue qin, const Queue qout, GenCtrl
                     V3 n = normalize(normal);                        // reflect(), utils.cpp:1167-1182
                     V3 dir = vsub(d, sscale(2.0 * dot(d, n), n));
                     c0 = true;
-                    c0o = vadd(r.point, sscale(S.shadow_eps, n));
+                    c0o = vadd(P, sscale(S.shadow_eps, n));
                     c0d = normalize(dir);
                     c0w = vmul(W, sscale(Fr, ld3(m.mirror)));
                 }
@@ -731,17 +909,17 @@ k_trace(const Scene S, const Frame F, const Queue qin, const Queue qout, GenCtrl
                     V3 n = normalize(normal);
                     V3 dir = vsub(d, sscale(2.0 * dot(d, n), n));
                     c0 = true;
-                    c0o = vadd(r.point, sscale(S.shadow_eps, n));
+                    c0o = vadd(P, sscale(S.shadow_eps, n));
                     c0d = normalize(dir);
                     c0w = tir ? W : vscale(W, Fr);
                     if (!tir) {
                         double cosPhi = sqrt(smax(0.0, 1.0 - s2));
                         V3 wt = vsub(vscale(vadd(d, vscale(normal, cosT)), eta), vscale(normal, cosPhi));
                         c1 = true;
-                        c1o = vsub(r.point, sscale(S.shadow_eps, normalize(normal)));
+                        c1o = vsub(P, sscale(S.shadow_eps, normalize(normal)));
                         c1d = normalize(wt);
                         c1w = vscale(W, 1.0 - Fr);
-                        c1beer = entering ? r.mat : -1;
+                        c1beer = entering ? mat : -1;
                     }
                 }
             } else {                                                 // utils.cpp:995-1038
@@ -749,10 +927,10 @@ k_trace(const Scene S, const Frame F, const Queue qin, const Queue qout, GenCtrl
                 lobe_a = ld3(m.diffuse);
                 lobe_s = ld3(m.specular);
                 if (m.is_mirror && deeper) {
-                    V3 n = normalize(r.sn);
+                    V3 n = normalize(sn);
                     V3 dir = vsub(d, sscale(2.0 * dot(d, n), n));
                     c0 = true;
-                    c0o = vadd(r.point, sscale(S.shadow_eps, n));
+                    c0o = vadd(P, sscale(S.shadow_eps, n));
                     c0d = normalize(dir);
                     c0w = vmul(W, ld3(m.mirror));
                 }
@@ -763,12 +941,12 @@ k_trace(const Scene S, const Frame F, const Queue qin, const Queue qout, GenCtrl
         // unshadowed contribution (utils.cpp:887-913, 1008-1038); isInShadow: utils.cpp:1066-1084.
         const bool lit = shade && mtype != RTX_MAT_DIELECTRIC;
         for (int li = 0; li < S.n_lights; li++) {
-            V3 so = o, sd = d, sw = W;
+            V3 so = P, sd = d, sw = W;
             double dist_to_light = 0.0;
             if (lit) {
                 const Light& L = S.lights[li];
                 V3 lp = ld3(L.p);
-                V3 lv = vsub(lp, r.point);
+                V3 lv = vsub(lp, P);
                 double d2 = dot(lv, lv);
                 double dist = sqrt(d2);
                 V3 ldir = vscale(lv, 1.0 / dist);
@@ -782,27 +960,15 @@ k_trace(const Scene S, const Frame F, const Queue qin, const Queue qout, GenCtrl
                     V3 diffuse = vscale(vscale(vmul(lobe_a, ld3(L.i)), df), atten);
                     contrib = vadd(diffuse, contrib);
                 }
-                so = vadd(r.point, sscale(S.shadow_eps, r.gn));
-                sd = normalize(vsub(lp, r.point));
+                so = vadd(P, sscale(S.shadow_eps, gn));
+                sd = normalize(vsub(lp, P));
                 sw = vmul(W, contrib);
-                dist_to_light = sqrt(dot(vsub(lp, r.point), vsub(lp, r.point)));
+                dist_to_light = sqrt(dot(vsub(lp, P), vsub(lp, P)));
             }
-            emit(qout, &next->count, &next->overflow, lit, so, sd, sw, dist_to_light, pixel, RTX_META(0, 1, -1));
+            emit(qout, next, true, lit, so, sd, sw, dist_to_light, pixel, 0u);
         }
-        emit(qout, &next->count, &next->overflow, c0, c0o, c0d, c0w, 0.0, pixel, RTX_META(depth + 1, 0, -1));
-        emit(qout, &next->count, &next->overflow, c1, c1o, c1d, c1w, 0.0, pixel, RTX_META(depth + 1, 0, c1beer));
-    }
-
-    if (COUNT && counters) {
-        // wave reduction, one set of atomics per wave
-        unsigned long long v[9] = {n_rays, n_primary, n_shadow, n_secondary, tl.node_visits, tl.tri_tests,
-                                   tl.world_box, tl.obj_trav, tl.tlas_visits};
-#pragma unroll
-        for (int k = 0; k < 9; k++) {
-            unsigned long long x = v[k];
-            for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off);
-            if (lane == 0 && x) atomicAdd(((unsigned long long*)counters) + k, x);
-        }
+        emit(qout, next, false, c0, c0o, c0d, c0w, 0.0, pixel, RTX_META(depth + 1, -1));
+        emit(qout, next, false, c1, c1o, c1d, c1w, 0.0, pixel, RTX_META(depth + 1, c1beer));
     }
 }
 
