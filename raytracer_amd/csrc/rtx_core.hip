@@ -8,6 +8,7 @@
 #include <climits>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <numeric>
 #include <string>
@@ -71,7 +72,7 @@ struct rtx_scene {
     uint32_t queue_capacity = 0;    // rays per queue, grows on overflow and is then kept
     DevBuf materials, lights, xforms, planes, spheres, ftris, meshes, insts, nodes, tris, tri_gn, tri_vn,
         tlas, tlas_order;
-    DevBuf accum, rgb, aov, ctrl, counters, queue[2], hitbuf;
+    DevBuf accum, rgb, aov, ctrl, counters, queue[2], hitbuf, launch;
     ~rtx_scene() {
         if (ev0) (void)hipEventDestroy(ev0);
         if (ev1) (void)hipEventDestroy(ev1);
@@ -410,7 +411,7 @@ Queue make_queue(void* base, uint32_t cap) {
     return q;
 }
 constexpr size_t kRayBytes = 10 * 8 + 2 * 4;
-constexpr size_t kHitBytes = 10 * 8 + 4;
+constexpr size_t kHitBytes = 12 * 8 + 7 * 4;
 
 HitBuf make_hitbuf(void* base, size_t cap) {
     HitBuf h;
@@ -420,7 +421,9 @@ HitBuf make_hitbuf(void* base, size_t cap) {
     h.px = (double*)take(8); h.py = (double*)take(8); h.pz = (double*)take(8);
     h.gx = (double*)take(8); h.gy = (double*)take(8); h.gz = (double*)take(8);
     h.sx = (double*)take(8); h.sy = (double*)take(8); h.sz = (double*)take(8);
-    h.code = (int32_t*)take(4);
+    h.beta = (double*)take(8); h.gamma = (double*)take(8);
+    h.code = (int32_t*)take(4); h.mat = (int32_t*)take(4); h.kind = (int32_t*)take(4);
+    h.container = (int32_t*)take(4); h.face = (int32_t*)take(4); h.tri = (int32_t*)take(4); h.src = (int32_t*)take(4);
     return h;
 }
 
@@ -585,33 +588,48 @@ int rtx_render(rtx_scene* sc, const rtx_camera* cam, int32_t tw, int32_t th, int
         HIP_TRY(sc->queue[1].ensure((size_t)sc->queue_capacity * kRayBytes));
         const size_t hit_cap = std::max<size_t>(sc->queue_capacity, (size_t)n_items0);
         HIP_TRY(sc->hitbuf.ensure(hit_cap * kHitBytes));
-        Queue q[2] = {make_queue(sc->queue[0].p, sc->queue_capacity), make_queue(sc->queue[1].p, sc->queue_capacity)};
-        const HitBuf hb = make_hitbuf(sc->hitbuf.p, hit_cap);
+        Launch launch;
+        launch.S = sc->dev; launch.F = F;
+        launch.q[0] = make_queue(sc->queue[0].p, sc->queue_capacity);
+        launch.q[1] = make_queue(sc->queue[1].p, sc->queue_capacity);
+        launch.hb = make_hitbuf(sc->hitbuf.p, hit_cap);
+        HIP_TRY(sc->launch.ensure(sizeof(Launch)));
+        // pageable source: the copy is staged before the call returns, so `launch` may go out of scope
+        HIP_TRY(hipMemcpyAsync(sc->launch.p, &launch, sizeof launch, hipMemcpyHostToDevice, sc->stream));
+        const Launch* lp = (const Launch*)sc->launch.p;
 
         HIP_TRY(hipMemsetAsync(sc->ctrl.p, 0, (size_t)(G + 1) * sizeof(GenCtrl), sc->stream));
         HIP_TRY(hipMemsetAsync(sc->accum.p, 0, (size_t)n_local_px * 3 * sizeof(double), sc->stream));
         if (sc->counters_on) HIP_TRY(hipMemsetAsync(sc->counters.p, 0, sizeof(Counters), sc->stream));
+        // RTX_AMD_GEN_TIMING=1 (development aid): per-generation kernel times on stderr
+        static const bool gen_timing = getenv("RTX_AMD_GEN_TIMING") != nullptr;
+        std::vector<hipEvent_t> gev;
+        if (gen_timing) {
+            gev.resize((size_t)2 * G + 1);
+            for (hipEvent_t& e : gev) HIP_TRY(hipEventCreate(&e));
+        }
         HIP_TRY(hipEventRecord(sc->ev0, sc->stream));
         for (int gen = 0; gen < G; gen++) {
+            if (gen_timing) HIP_TRY(hipEventRecord(gev[2 * gen], sc->stream));
             unsigned blocks = persistent_blocks;
             if (gen == 0) blocks = (unsigned)std::min<int64_t>(persistent_blocks, (n_items0 + 255) / 256);
-            const Queue& qin = q[(gen + 1) & 1];     // rays of this generation
-            const Queue& qout = q[gen & 1];          // rays it spawns
             rtx_hit_id* aov = (gen == 0 && hit_ids) ? (rtx_hit_id*)sc->aov.p : nullptr;
             if (sc->counters_on)
-                hipLaunchKernelGGL(k_trace<true>, dim3(blocks), dim3(256), 0, sc->stream, sc->dev, F, qin, hb,
-                                   (GenCtrl*)sc->ctrl.p, gen, (double*)sc->accum.p, aov, (Counters*)sc->counters.p);
+                hipLaunchKernelGGL(k_trace<true>, dim3(blocks), dim3(256), 0, sc->stream, lp, (GenCtrl*)sc->ctrl.p, gen,
+                                   (double*)sc->accum.p, aov, (Counters*)sc->counters.p);
             else
-                hipLaunchKernelGGL(k_trace<false>, dim3(blocks), dim3(256), 0, sc->stream, sc->dev, F, qin, hb,
-                                   (GenCtrl*)sc->ctrl.p, gen, (double*)sc->accum.p, aov, (Counters*)nullptr);
+                hipLaunchKernelGGL(k_trace<false>, dim3(blocks), dim3(256), 0, sc->stream, lp, (GenCtrl*)sc->ctrl.p, gen,
+                                   (double*)sc->accum.p, aov, (Counters*)nullptr);
+            if (gen_timing) HIP_TRY(hipEventRecord(gev[2 * gen + 1], sc->stream));
             // the last generation holds shadow rays only: nothing left to shade
             if (gen + 1 < G)
-                hipLaunchKernelGGL(k_shade, dim3(blocks), dim3(256), 0, sc->stream, sc->dev, F, qin, qout, hb,
-                                   (GenCtrl*)sc->ctrl.p, gen, (double*)sc->accum.p);
+                hipLaunchKernelGGL(k_shade, dim3(blocks), dim3(256), 0, sc->stream, lp, (GenCtrl*)sc->ctrl.p, gen,
+                                   (double*)sc->accum.p);
         }
         const unsigned n_values = (unsigned)(n_local_px * 3);
         hipLaunchKernelGGL(k_resolve, dim3((n_values + 255) / 256), dim3(256), 0, sc->stream,
                            (const double*)sc->accum.p, (uint8_t*)sc->rgb.p, n_values);
+        if (gen_timing) HIP_TRY(hipEventRecord(gev[2 * G], sc->stream));
         HIP_TRY(hipEventRecord(sc->ev1, sc->stream));
         HIP_TRY(hipGetLastError());
         std::vector<GenCtrl> ctrl((size_t)G + 1);
@@ -620,6 +638,17 @@ int rtx_render(rtx_scene* sc, const rtx_camera* cam, int32_t tw, int32_t th, int
         float ms = 0.f;
         HIP_TRY(hipEventElapsedTime(&ms, sc->ev0, sc->ev1));
         kernel_ms += ms;
+        if (gen_timing) {
+            for (int gen = 0; gen < G; gen++) {
+                float t_trace = 0.f, t_shade = 0.f;
+                (void)hipEventElapsedTime(&t_trace, gev[2 * gen], gev[2 * gen + 1]);
+                (void)hipEventElapsedTime(&t_shade, gev[2 * gen + 1], gev[2 * gen + 2]);
+                const unsigned long long c = gen == 0 ? (unsigned long long)n_items0 : ctrl[gen].counts;
+                fprintf(stderr, "[rtx] gen %d: radiance %u shadow %u trace %.1f us shade(+resolve) %.1f us\n", gen,
+                        (unsigned)c, (unsigned)(c >> 32), t_trace * 1e3, t_shade * 1e3);
+            }
+            for (hipEvent_t& e : gev) (void)hipEventDestroy(e);
+        }
         bool overflow = false;
         uint32_t peak = 0;
         for (const GenCtrl& c : ctrl) {
@@ -645,6 +674,15 @@ int rtx_render(rtx_scene* sc, const rtx_camera* cam, int32_t tw, int32_t th, int
     Counters ctr{};
     if (sc->counters_on) HIP_TRY(hipMemcpyAsync(&ctr, sc->counters.p, sizeof ctr, hipMemcpyDeviceToHost, sc->stream));
     HIP_TRY(hipStreamSynchronize(sc->stream));
+    if (sc->counters_on && getenv("RTX_AMD_GEN_TIMING"))
+        fprintf(stderr, "[rtx] trace waves %llu: ticks/wave total %.0f traverse %.0f service %.0f; service passes %llu "
+                "(%.0f ticks each), traversal steps %llu (%.0f ticks each; fetch %.0f, pop %.0f)\n", ctr.waves,
+                (double)ctr.clk_total / std::max(1ull, ctr.waves), (double)ctr.clk_traverse / std::max(1ull, ctr.waves),
+                (double)ctr.clk_service / std::max(1ull, ctr.waves), ctr.service_passes,
+                (double)ctr.clk_service / std::max(1ull, ctr.service_passes), ctr.inner_steps + ctr.leaf_steps,
+                (double)ctr.clk_traverse / std::max(1ull, ctr.inner_steps + ctr.leaf_steps),
+                (double)ctr.clk_fetch / std::max(1ull, ctr.inner_steps + ctr.leaf_steps),
+                (double)ctr.clk_pop / std::max(1ull, ctr.inner_steps + ctr.leaf_steps));
     if (stats) {
         stats->rays = ctr.rays; stats->primary_rays = ctr.primary; stats->shadow_rays = ctr.shadow;
         stats->secondary_rays = ctr.secondary; stats->node_visits = ctr.node_visits; stats->tri_tests = ctr.tri_tests;

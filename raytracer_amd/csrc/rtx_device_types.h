@@ -119,14 +119,19 @@ struct Queue {
 };
 
 // Closest-hit records of the radiance rays of one generation (structure of arrays, indexed
-// by queue slot; by work item for generation 0).  code: -1 miss, 0 hit without material,
-// m+1 hit with material m.
+// by queue slot; by work item for generation 0).  During traversal the slot IS the ray's
+// Intersection record (scene.h:248-264): every event that writes the reference's record stores
+// the same fields here.  The normals are stored as the reference's object loop leaves them; the
+// tail of intersect() (normalisation, vertex-normal interpolation, utils.cpp:807-853) is
+// applied by the shading kernel.  code: -2 no ray (padding item), -1 miss, 1 hit.
 struct HitBuf {
     double* dist;
     double* px; double* py; double* pz;
     double* gx; double* gy; double* gz;     // geometric normal
     double* sx; double* sy; double* sz;     // shading normal
-    int32_t* code;
+    double* beta; double* gamma;
+    int32_t* code;                          // completion status, written last
+    int32_t* mat; int32_t* kind; int32_t* container; int32_t* face; int32_t* tri; int32_t* src;
 };
 
 // Control block of one generation.  counts packs the number of radiance rays (low half) and
@@ -138,10 +143,22 @@ struct GenCtrl {
     unsigned overflow, pad[3];
 };
 
+// Everything the kernels of one frame read besides the bulk arrays, kept in device memory so
+// that kernels take one pointer (scalar loads) instead of a few hundred bytes of by-value
+// arguments held in SGPRs.  q[g & 1] receives the rays spawned by generation g.
+struct Launch {
+    Scene S;
+    Frame F;
+    Queue q[2];
+    HitBuf hb;
+};
+
 struct Counters {
     unsigned long long rays, primary, shadow, secondary;
     unsigned long long node_visits, tri_tests, world_box_tests, object_traversals, tlas_visits;
     unsigned long long inner_steps, inner_lanes, leaf_steps, leaf_lanes;
+    // time split of the trace kernel's waves, in shader-clock ticks summed over waves
+    unsigned long long service_passes, clk_traverse, clk_service, clk_total, waves, clk_fetch, clk_pop;
 };
 
 }  // namespace rtxdev

@@ -21,9 +21,12 @@
 // stack, but the 128-byte node (or 80-byte triangle) records the lanes need are fetched by
 // the whole wave: eight lanes read one record as eight adjacent 16-byte pieces, so one
 // load instruction touches 8 records x 128 contiguous bytes instead of 64 scattered
-// 16-byte pieces, and the record is handed to its owner lane through a per-wave LDS row.
+// 16-byte pieces.  The loads are LDS-DMA (global_load_lds_dwordx4): the pieces land directly
+// in the owner lane's 128-byte LDS row without passing through registers.
 // Lanes alternate between an inner-node phase and a leaf phase by majority vote
-// (while-while traversal), which keeps each lane's own visit order untouched.
+// (while-while traversal), which keeps each lane's own visit order untouched.  Lanes are
+// refilled dynamically: a lane that finishes its ray (or the current object of its ray) picks
+// up its next job while the other lanes keep traversing (see "Per-lane ray state" below).
 //
 // All geometry arithmetic is FP64 in the reference's operation order and this file must be
 // compiled with -ffp-contract=off: primary-hit identity has to match the reference bit for
@@ -164,221 +167,71 @@ RTX_DEV bool tri_test(const double* T, V3 o, V3 d, double t_min, double eps, dou
 }
 
 struct Tally { unsigned node_visits, tri_tests, world_box, obj_trav, tlas_visits;
-               unsigned inner_steps, inner_lanes, leaf_steps, leaf_lanes; };   // wave-step occupancy (lane 0 only)
+               unsigned inner_steps, inner_lanes, leaf_steps, leaf_lanes;       // wave-step occupancy (lane 0 only)
+               unsigned rays, primary, shadow, secondary;
+               unsigned passes;                                                  // service passes (lane 0)
+               unsigned long long clk_trav, clk_serv, clk_total, clk_fetch, clk_pop; };              // shader-clock ticks (lane 0)
 
 #define RTX_STACK 64
-#define RTX_ROW_DOUBLES 18          // 144-byte LDS row per lane: 128-byte record + 16 bytes of
-                                    // padding so that 16 lanes' ds_read_b128 hit distinct banks
+#define RTX_ROW_DOUBLES 16          // one 128-byte LDS row per lane
 
 RTX_DEV unsigned lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 
-// Per-wave context: this wave's 64 LDS rows and the lane number.
-struct Wave { double* rows; unsigned lane; };
+// Address-space-qualified views: LDS rows and the private traversal stack are passed to
+// out-of-line code through these so that ds_* and scratch_* instructions are used (a plain
+// pointer would be generic and turn every access into a flat_* instruction).
+typedef __attribute__((address_space(3))) double lds_double;
+typedef double v2d __attribute__((ext_vector_type(2)));
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) v2d lds_v2d;
+typedef __attribute__((address_space(5))) v4i priv_v4i;
 
-// Wave-cooperative gather of one fixed-size record per requesting lane into that lane's LDS
-// row.  `mask` = ballot of the requesting lanes, `index` = record number (valid in requesting
-// lanes), records start at base + index*STRIDE and are NCHUNK*16 bytes long.  Eight lanes
-// serve one owner (owner = 8g + lane/8, piece = lane%8 in round g), so each load instruction
-// reads up to 8 whole records.  Must be executed by every lane of the wave.
-template <int NCHUNK, int STRIDE>
-RTX_DEV void coop_fetch(const Wave& wv, unsigned long long mask, int index, const char* __restrict__ base) {
-    const unsigned sub = wv.lane >> 3, piece = wv.lane & 7u;
+// Per-wave context: this wave's 64 LDS rows and the lane number.
+struct Wave { lds_double* rows; unsigned lane; };
+
+// Wave-cooperative gather of one record per requesting lane into that lane's 128-byte LDS
+// row.  `mask` = ballot of the requesting lanes; `key` (valid in requesting lanes) names the
+// record: key >= 0 is BLAS node `key` (128 bytes), key < 0 is triangle `key & 0x7fffffff`
+// (80 bytes).  In round g lane l serves owner 8g + l/8, so one LDS-DMA instruction
+// (destination = wave-uniform base + 16*lane) fills the rows of owners 8g..8g+7 with up to 8
+// whole records.  To keep the owners' later 16-byte row reads free of bank conflicts the
+// pieces are stored XOR-swizzled: slot s of owner w holds piece s ^ ((w >> 1) & 7) -- applied
+// to the *source* address here and to the slot index in row_read.  Must be executed by every
+// lane of the wave.
+RTX_DEV void coop_fetch(const Wave& wv, unsigned long long mask, int key, const char* __restrict__ nodes,
+                        const char* __restrict__ tris) {
+    const unsigned sub = wv.lane >> 3, slot = wv.lane & 7u;
 #pragma unroll
     for (int g = 0; g < 8; g++) {
         const unsigned gm = (unsigned)(mask >> (8 * g)) & 0xFFu;        // wave-uniform
         if (gm) {
             const int owner = 8 * g + (int)sub;
-            const int oidx = __shfl(index, owner);
-            if (((gm >> sub) & 1u) && (int)piece < NCHUNK) {
-                const float4 v = *(const float4*)(base + (size_t)oidx * STRIDE + piece * 16u);
-                *(float4*)((char*)wv.rows + owner * (RTX_ROW_DOUBLES * 8) + piece * 16u) = v;
+            const int okey = __shfl(key, owner);
+            const unsigned piece = slot ^ (((unsigned)owner >> 1) & 7u);
+            const bool is_tri = okey < 0;
+            if (((gm >> sub) & 1u) && (!is_tri || piece < 5u)) {
+                const unsigned idx = (unsigned)okey & 0x7FFFFFFFu;
+                const char* gp = (is_tri ? tris + (size_t)idx * sizeof(Tri) : nodes + (size_t)idx * sizeof(Node)) + piece * 16u;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gp,
+                                                 (__attribute__((address_space(3))) void*)(wv.rows + g * 8 * RTX_ROW_DOUBLES),
+                                                 16, 0, 0);
             }
         }
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
 }
 
-// BLAS traversal with the visit order and the visited set of bvh.cpp:104-185: children are
-// ordered near/far by the sign of dir[splitAxis] (near popped first), a node is entered iff
-// its box test passes with the bound current at the moment the reference would pop it.
-// Both children's boxes are evaluated when their parent is visited; the far child is pushed
-// together with its entry distance and re-checked against the (possibly smaller) bound when
-// popped, which is the same predicate the reference evaluates at that moment.
-//
-// Called by the whole wave; `go` marks the lanes that actually traverse (their own mesh,
-// ray and bound).  Returns per lane whether a closer triangle was found.
-template <bool COUNT>
-RTX_DEV bool blas_traverse(const Scene& S, const Wave& wv, bool go, int mesh_index, V3 o, V3 d, double& t_min,
-                           int& best_tri, double& best_beta, double& best_gamma, Tally& tl) {
-    const Slab sl = make_slab(o, d);
-    bool alive = false;
-    int cur_ref = 0, cur_cnt = 0;
-    if (go) {
-        const Mesh& m = S.meshes[mesh_index];
-        double enter;
-        alive = box_enter(m.rmin, m.rmax, sl, enter) && (t_min >= enter);
-        cur_ref = m.root_ref; cur_cnt = m.root_count;
+// Read the first NCHUNK 16-byte pieces of this lane's row (undoing the swizzle) into out[].
+template <int NCHUNK>
+RTX_DEV void row_read(const Wave& wv, double* out) {
+    const lds_v2d* r2 = (const lds_v2d*)(wv.rows + wv.lane * RTX_ROW_DOUBLES);
+    const unsigned sw = (wv.lane >> 1) & 7u;
+#pragma unroll
+    for (int p = 0; p < NCHUNK; p++) {
+        const v2d v = r2[(unsigned)p ^ sw];
+        out[2 * p] = v.x; out[2 * p + 1] = v.y;
     }
-    int stk_ref[RTX_STACK], stk_cnt[RTX_STACK];
-    double stk_t[RTX_STACK];
-    int sp = 0;
-    bool found = false;
-    const double* row = wv.rows + wv.lane * RTX_ROW_DOUBLES;
-
-    while (true) {
-        const bool at_inner = alive && cur_cnt == 0;
-        const bool at_leaf = alive && cur_cnt > 0;
-        const unsigned long long m_inner = __ballot(at_inner);
-        const unsigned long long m_leaf = __ballot(at_leaf);
-        if ((m_inner | m_leaf) == 0ull) break;
-        bool need_pop = false;
-        // Phase choice by majority: a leaf step costs several inner steps, so leaves wait until
-        // they clearly outnumber the lanes still descending.
-        if (m_inner != 0ull && 2 * __popcll(m_inner) >= __popcll(m_leaf)) {
-            if (COUNT && wv.lane == 0) { tl.inner_steps++; tl.inner_lanes += (unsigned)__popcll(m_inner); }
-            coop_fetch<8, 128>(wv, m_inner, cur_ref, (const char*)S.nodes);
-            if (at_inner) {
-                if (COUNT) tl.node_visits++;
-                const int* ri = (const int*)(row + 12);
-                double el, er;
-                const bool okl = box_enter(row + 0, row + 3, sl, el) && (t_min >= el);
-                const bool okr = box_enter(row + 6, row + 9, sl, er) && (t_min >= er);
-                const int lref = ri[0], lcnt = ri[1], rref = ri[2], rcnt = ri[3], axis = ri[4];
-                const double da = axis == 0 ? d.x : (axis == 1 ? d.y : d.z);
-                const bool left_near = da >= 0.0;
-                const int nref = left_near ? lref : rref, ncnt = left_near ? lcnt : rcnt;
-                const int fref = left_near ? rref : lref, fcnt = left_near ? rcnt : lcnt;
-                const bool okn = left_near ? okl : okr, okf = left_near ? okr : okl;
-                const double ef = left_near ? er : el;
-                if (okn) {
-                    if (okf && sp < RTX_STACK) { stk_ref[sp] = fref; stk_cnt[sp] = fcnt; stk_t[sp] = ef; sp++; }
-                    cur_ref = nref; cur_cnt = ncnt;
-                } else if (okf) {
-                    cur_ref = fref; cur_cnt = fcnt;
-                } else {
-                    need_pop = true;
-                }
-            }
-            __builtin_amdgcn_wave_barrier();
-        } else {
-            // leaf phase: triangle k of every leaf lane, in leaf order
-            for (int k = 0;; k++) {
-                const bool want = at_leaf && k < cur_cnt;
-                const unsigned long long mk_ = __ballot(want);
-                if (mk_ == 0ull) break;
-                if (COUNT && wv.lane == 0) { tl.leaf_steps++; tl.leaf_lanes += (unsigned)__popcll(mk_); }
-                coop_fetch<5, 80>(wv, mk_, cur_ref + k, (const char*)S.tris);
-                if (want) {
-                    const int ti = cur_ref + k;
-                    if (COUNT) tl.tri_tests++;
-                    bool culled = false;
-                    if (S.cull) {
-                        const double* g = S.tri_gn + 3 * (size_t)ti;
-                        culled = d.x * g[0] + d.y * g[1] + d.z * g[2] > 0.0;
-                    }
-                    double t, b, g2;
-                    if (!culled && tri_test(row, o, d, t_min, S.isect_eps, t, b, g2)) {
-                        t_min = t; best_tri = ti; best_beta = b; best_gamma = g2; found = true;
-                    }
-                }
-                __builtin_amdgcn_wave_barrier();
-            }
-            need_pop = at_leaf;
-        }
-        if (need_pop) {
-            alive = false;
-            while (sp > 0) {
-                --sp;
-                if (t_min >= stk_t[sp]) { cur_ref = stk_ref[sp]; cur_cnt = stk_cnt[sp]; alive = true; break; }
-            }
-        }
-    }
-    return found;
-}
-
-// Fields a successful triangle test writes (utils.cpp:370-381) + kind (bvh.cpp:162).
-RTX_DEV void write_tri_hit(const Scene& S, Rec& r, int tri, double t, double beta, double gamma,
-                           int material, int container) {
-    const Tri& T = S.tris[tri];
-    V3 a = ld3(T.a), e1 = ld3(T.e1), e2 = ld3(T.e2);
-    r.hit = 1;
-    r.dist = t;
-    r.point = vadd(vadd(a, sscale(beta, e1)), sscale(gamma, e2));
-    r.gn = ld3(S.tri_gn + 3 * (size_t)tri);
-    r.sn = r.gn;
-    r.beta = beta; r.gamma = gamma;
-    r.mat = material;
-    r.container = container;
-    r.face = T.face;
-    r.tri = tri;
-    r.kind = RTX_KIND_MESH;
-}
-
-// rayHitsMesh (utils.cpp:396-669) for mesh `mi` under transform `xfi` (-1: none).  Called by
-// the whole wave; lanes with act == false only help with the cooperative fetches.
-template <bool COUNT>
-RTX_DEV bool mesh_hit(const Scene& S, const Wave& wv, bool act, V3 o, V3 d, int mi, int xfi, int material,
-                      double& t_min, Rec& r, Tally& tl) {
-    bool go = act;
-    if (go && S.meshes[mi].n_faces <= 0) go = false;
-    V3 ro = o, rd = d;
-    const double original_t_min = t_min;
-    if (go && xfi >= 0) {
-        const Xform& xf = S.xforms[xfi];
-        if (xf.has_bounds) {
-            if (COUNT) tl.world_box++;
-            const Slab sl = make_slab(o, d);
-            double enter;
-            if (!box_enter(xf.bmin, xf.bmax, sl, enter) || !(t_min >= enter)) go = false;
-        }
-        if (go) {
-            if (COUNT) tl.obj_trav++;
-            ro = xf_point(xf.inv, o);
-            rd = normalize_f32(xf_dir(xf.inv, d));
-        }
-    }
-    int tri = -1;
-    double beta = 0, gamma = 0;
-    const bool found = blas_traverse<COUNT>(S, wv, go, mi, ro, rd, t_min, tri, beta, gamma, tl);
-    if (!(go && found)) return false;
-    write_tri_hit(S, r, tri, t_min, beta, gamma, material, mi);
-    if (xfi < 0) return true;
-
-    const Xform& xf = S.xforms[xfi];
-    const Mesh& m = S.meshes[mi];
-    V3 wp = xf_point(xf.m, r.point);
-    double dx = wp.x - o.x, dy = wp.y - o.y, dz = wp.z - o.z;
-    double wd = (double)sqrtf((float)(dx * dx + dy * dy + dz * dz));
-    if (wd >= original_t_min) {           // utils.cpp:567-570: bound restored, record is not
-        t_min = original_t_min;
-        return false;
-    }
-    V3 wg = normalize_f32(xf_dir(xf.nrm, r.gn));
-    V3 ws;
-    if (m.smooth && m.has_vn) {           // utils.cpp:589-621
-        double u = r.beta, v = r.gamma, w = 1.0 - u - v;
-        const double* vn = S.tri_vn + 9 * (size_t)tri;
-        double nx = w * vn[0] + u * vn[3] + v * vn[6];
-        double ny = w * vn[1] + u * vn[4] + v * vn[7];
-        double nz = w * vn[2] + u * vn[5] + v * vn[8];
-        double nlen = (double)sqrtf((float)(nx * nx + ny * ny + nz * nz));
-        double ninv = 1.0 / nlen;
-        nx *= ninv; ny *= ninv; nz *= ninv;
-        ws = xf_dir(xf.nrm, mk(nx, ny, nz));
-    } else {
-        ws = xf_dir(xf.nrm, r.sn);
-    }
-    {
-        double slen = (double)sqrtf((float)(ws.x * ws.x + ws.y * ws.y + ws.z * ws.z));
-        double sinv = 1.0 / slen;
-        ws.x *= sinv; ws.y *= sinv; ws.z *= sinv;
-    }
-    if (dot(wg, d) > 0.0) { wg = vneg(wg); ws = vneg(ws); }
-    r.point = wp; r.gn = wg; r.sn = ws; r.dist = wd;
-    t_min = wd;
-    r.kind = RTX_KIND_MESH;
-    r.container = -2;
-    return true;
 }
 
 // utils.cpp:160-219
@@ -544,80 +397,254 @@ RTX_DEV void tlas_collect(const Scene& S, const Slab& sl, double t_min, int last
     }
 }
 
-// Closest-hit query with the reference's object order and state machine (utils.cpp:671-865).
-// Executed by the whole wave; `active` marks the lanes that carry a ray.
+// ---------------------------------------------------------------------------------------
+// Per-lane ray state of the trace kernel.
+//
+// A lane owns one ray at a time and walks it through the reference's object sequence
+// (utils.cpp:671-865): planes -> free triangles -> meshes (in index order) -> spheres ->
+// instances (in index order).  Meshes and instances are *traversal jobs*: (mesh, object-space
+// ray, bound).  The wave runs all its lanes' jobs together in one cooperative traversal
+// loop; a lane whose job ends waits until enough lanes need service, then the wave runs one
+// divergent "service pass" that finishes jobs, selects each lane's next job, retires
+// completed rays and claims fresh rays for idle lanes.  This keeps the lanes of a wave busy
+// although rays differ wildly in length.
+//
+// Only what a traversal step touches lives in registers.  The Intersection record
+// (scene.h:248-264) lives in HBM, in the ray's slot of the hit buffer: the few events that
+// write it (an accepted hit, or the half-written record of utils.cpp:567-570 / 719-721)
+// store exactly the fields the reference writes at that point, so the slot always holds
+// what the reference's `intersection` holds; registers keep only the bound, the record's
+// distance and the hit flag.
+// ---------------------------------------------------------------------------------------
+enum { LS_EMPTY = 0, LS_NEED_JOB = 1, LS_JOB_DONE = 2, LS_IN_JOB = 3 };
+
+#define RTX_SERVICE_THRESHOLD 24     // lanes waiting for service that trigger a service pass
+#define RTX_CHUNK 256                // rays a wave claims per atomic
+#ifndef RTX_TRACE_WAVES
+#define RTX_TRACE_WAVES 4            // waves per SIMD the trace kernel is compiled for (<= 128 VGPRs)
+#endif
+
+struct Lane {
+    V3 d;                   // world-space direction (the origin is re-read when needed)
+    double t_min, dist;     // current bound; Intersection::distance of the record
+    unsigned slot;          // queue slot (work item for generation 0) = hit-buffer slot
+    int is_shadow, hit;
+    // object iterator: it <= n_meshes: meshes (job = mesh it-1); it > n_meshes: instances (job = last)
+    int it, last, more;
+    int buf[RTX_CAND];
+    // current traversal job
+    double orig_t_min;
+    V3 ro, rd;
+    double ix, iy, iz;
+    int par;
+    int cur_ref, cur_cnt, sp, btri;
+    int state;
+    v4i top;                // top stack entry (valid while sp > 0)
+};
+
+// Where a lane's record goes.  Shadow rays need only (hit, distance), which stay in registers.
+struct RecOut {
+    HitBuf hb; unsigned slot; bool on; bool ids;
+    RTX_DEV void geom(double dist, V3 p, V3 g, V3 s) const {
+        if (!on) return;
+        hb.dist[slot] = dist;
+        hb.px[slot] = p.x; hb.py[slot] = p.y; hb.pz[slot] = p.z;
+        hb.gx[slot] = g.x; hb.gy[slot] = g.y; hb.gz[slot] = g.z;
+        hb.sx[slot] = s.x; hb.sy[slot] = s.y; hb.sz[slot] = s.z;
+    }
+    RTX_DEV void bary(double beta, double gamma, int face, int tri) const {
+        if (!on) return;
+        hb.beta[slot] = beta; hb.gamma[slot] = gamma; hb.face[slot] = face; hb.tri[slot] = tri;
+    }
+    RTX_DEV void owner(int mat, int container) const { if (on) { hb.mat[slot] = mat; hb.container[slot] = container; } }
+    RTX_DEV void kind(int k) const { if (on) hb.kind[slot] = k; }
+    RTX_DEV void src(int s) const { if (on && ids) hb.src[slot] = s; }
+};
+
+RTX_DEV Slab lane_slab(const Lane& L) {
+    Slab s; s.ox = L.ro.x; s.oy = L.ro.y; s.oz = L.ro.z; s.ix = L.ix; s.iy = L.iy; s.iz = L.iz; s.par = L.par; return s;
+}
+
+// A fresh ray: empty record, then the classes that come before the meshes
+// (planes, utils.cpp:683-685; free triangles, utils.cpp:692-729).
 template <bool COUNT>
-RTX_DEV void intersect(const Scene& S, const Wave& wv, bool active, V3 o, V3 d, Rec& r, Tally& tl) {
-    double t_min = DBL_MAX;
-    r.hit = 0; r.dist = 0.0; r.beta = 0.0; r.gamma = 0.0;
-    r.point = mk(0, 0, 0); r.gn = mk(0, 0, 0); r.sn = mk(0, 0, 0);
-    r.kind = RTX_KIND_NONE; r.container = -1; r.face = -1; r.tri = -1; r.mat = -1; r.src = -1;
-    bool hit = false;
-
-    if (active) {
-        for (int i = 0; i < S.n_planes; i++) hit = plane_hit(S, o, d, i, t_min, r) || hit;
-        for (int i = 0; i < S.n_ftris; i++) free_tri_hit<COUNT>(S, o, d, i, t_min, r, hit, tl);
+RTX_DEV void ray_begin(const Scene& S, Lane& L, V3 o, const RecOut& out, Tally& tl) {
+    L.t_min = DBL_MAX;
+    L.dist = 0.0;
+    L.hit = 0;
+    if (S.n_planes > 0 || S.n_ftris > 0) {
+        Rec r;
+        r.hit = 0; r.dist = 0.0; r.beta = 0.0; r.gamma = 0.0;
+        r.point = mk(0, 0, 0); r.gn = mk(0, 0, 0); r.sn = mk(0, 0, 0);
+        r.kind = RTX_KIND_NONE; r.container = -1; r.face = -1; r.tri = -1; r.mat = -1; r.src = -1;
+        bool hit = false;
+        for (int i = 0; i < S.n_planes; i++) hit = plane_hit(S, o, L.d, i, L.t_min, r) || hit;
+        for (int i = 0; i < S.n_ftris; i++) free_tri_hit<COUNT>(S, o, L.d, i, L.t_min, r, hit, tl);
+        if (r.hit) {
+            out.geom(r.dist, r.point, r.gn, r.sn);
+            out.bary(r.beta, r.gamma, r.face, r.tri);
+            out.owner(r.mat, r.container);
+            out.kind(r.kind);
+            out.src(r.src);
+            L.dist = r.dist;
+        }
+        L.hit = hit ? 1 : 0;
     }
-    for (int i = 0; i < S.n_meshes; i++) {                      // wave-uniform loop
-        const Mesh& m = S.meshes[i];
-        if (mesh_hit<COUNT>(S, wv, active, o, d, i, m.xform, m.material, t_min, r, tl)) { hit = true; r.src = i; }
-    }
-    if (active)
-        for (int i = 0; i < S.n_spheres; i++) hit = sphere_hit(S, o, d, i, t_min, r) || hit;
+    L.it = 0; L.last = -1; L.more = 0;
+#pragma unroll
+    for (int k = 0; k < RTX_CAND; k++) L.buf[k] = INT_MAX;
+    L.state = LS_NEED_JOB;
+}
 
-    // Instances (utils.cpp:756-790).  The TLAS only selects candidates -- instances whose
-    // world box the ray meets within the current bound; a box missed now stays missed
-    // because the bound never grows.  Candidates are then replayed in ascending index,
-    // RTX_CAND at a time, through the reference's own per-instance logic.
-    if (S.n_insts > 0) {
-        const Slab sl = make_slab(o, d);
-        int last = -1;
-        bool more = active;
-        while (__ballot(more) != 0ull) {
-            int buf[RTX_CAND];
-#pragma unroll
-            for (int k = 0; k < RTX_CAND; k++) buf[k] = INT_MAX;
-            if (more) tlas_collect<COUNT>(S, sl, t_min, last, buf, tl);
-            const bool full = buf[RTX_CAND - 1] != INT_MAX;
-            bool have = more && buf[0] != INT_MAX;
-            while (__ballot(have) != 0ull) {
-                const int idx = buf[0];
-#pragma unroll
-                for (int q = 0; q + 1 < RTX_CAND; q++) buf[q] = buf[q + 1];
-                buf[RTX_CAND - 1] = INT_MAX;
-                int base_mesh = 0, xform = -1, material = -1;
-                if (have) {
-                    last = idx;
-                    const Inst& in = S.insts[idx];
-                    base_mesh = in.base_mesh; xform = in.xform; material = in.material;
+// Mesh, transform, material and producing-object id of the lane's current job.
+RTX_DEV void job_ids(const Scene& S, const Lane& L, int& mi, int& xfi, int& mat, int& src) {
+    if (L.it <= S.n_meshes) {
+        mi = L.it - 1;
+        const Mesh& m = S.meshes[mi];
+        xfi = m.xform; mat = m.material; src = mi;
+    } else {
+        const Inst& in = S.insts[L.last];
+        mi = in.base_mesh; xfi = in.xform; mat = in.material; src = S.n_meshes + L.last;
+    }
+}
+
+// Advance the lane's object iterator until an object needs traversal (returns true, job set
+// up: rayHitsMesh's prologue, utils.cpp:418-494 + the root test of bvh.cpp:132) or the
+// object sequence is exhausted (returns false).
+template <bool COUNT>
+RTX_DEV bool job_next(const Scene& S, Lane& L, V3 o, const RecOut& out, Tally& tl) {
+    while (true) {
+        int mi, xfi;
+        if (L.it < S.n_meshes) {                                     // utils.cpp:736-739
+            mi = L.it; L.it++;
+            xfi = S.meshes[mi].xform;
+        } else {
+            if (L.it == S.n_meshes) {                                // utils.cpp:746-748
+                L.it++;
+                if (S.n_spheres > 0) {
+                    Rec r;
+                    r.kind = -1; r.dist = 0.0; r.hit = 0; r.mat = -1; r.container = -1; r.src = -1;
+                    r.point = mk(0, 0, 0); r.gn = r.point; r.sn = r.point;
+                    bool hit = L.hit != 0;
+                    for (int i = 0; i < S.n_spheres; i++) hit = sphere_hit(S, o, L.d, i, L.t_min, r) || hit;
+                    if (r.kind != -1) {                              // fields a sphere hit writes, utils.cpp:269-291
+                        out.geom(r.dist, r.point, r.gn, r.sn);
+                        out.owner(r.mat, r.container);
+                        out.kind(r.kind);
+                        out.src(r.src);
+                        L.dist = r.dist;
+                    }
+                    L.hit = hit ? 1 : 0;
                 }
-                if (mesh_hit<COUNT>(S, wv, have, o, d, base_mesh, xform, material, t_min, r, tl)) {
-                    hit = true; r.src = S.n_meshes + idx;
-                }
-                have = have && buf[0] != INT_MAX;
+                L.more = S.n_insts > 0 ? 1 : 0;
             }
-            more = more && full;
+            // Instances (utils.cpp:756-790).  The TLAS only selects candidates -- instances
+            // whose world box the ray meets within the current bound; a box missed now stays
+            // missed because the bound never grows.  Candidates are replayed in ascending
+            // index, RTX_CAND at a time, through the reference's own per-instance logic.
+            if (L.buf[0] == INT_MAX) {
+                if (!L.more) return false;
+                const Slab ws = make_slab(o, L.d);
+                tlas_collect<COUNT>(S, ws, L.t_min, L.last, L.buf, tl);
+                L.more = L.buf[RTX_CAND - 1] != INT_MAX ? 1 : 0;
+                if (L.buf[0] == INT_MAX) return false;
+            }
+            const int idx = L.buf[0];
+#pragma unroll
+            for (int q = 0; q + 1 < RTX_CAND; q++) L.buf[q] = L.buf[q + 1];
+            L.buf[RTX_CAND - 1] = INT_MAX;
+            L.last = idx;
+            const Inst& in = S.insts[idx];
+            mi = in.base_mesh; xfi = in.xform;
         }
+        const Mesh& m = S.meshes[mi];
+        if (m.n_faces <= 0) continue;
+        V3 ro = o, rd = L.d;
+        if (xfi >= 0) {
+            const Xform& xf = S.xforms[xfi];
+            if (xf.has_bounds) {                                     // utils.cpp:446-466, 760-766
+                if (COUNT) tl.world_box++;
+                const Slab ws = make_slab(o, L.d);
+                double enter;
+                if (!box_enter(xf.bmin, xf.bmax, ws, enter) || !(L.t_min >= enter)) continue;
+            }
+            if (COUNT) tl.obj_trav++;
+            ro = xf_point(xf.inv, o);                                // utils.cpp:481-489
+            rd = normalize_f32(xf_dir(xf.inv, L.d));
+        }
+        const Slab sl = make_slab(ro, rd);
+        double enter;
+        if (!box_enter(m.rmin, m.rmax, sl, enter) || !(L.t_min >= enter)) continue;
+        L.orig_t_min = L.t_min;
+        L.ro = ro; L.rd = rd; L.ix = sl.ix; L.iy = sl.iy; L.iz = sl.iz; L.par = sl.par;
+        L.cur_ref = m.root_ref; L.cur_cnt = m.root_count; L.sp = 0; L.btri = -1;
+        return true;
     }
+}
 
-    if (!(active && hit)) { r.hit = 0; return; }
-    // utils.cpp:807-853.  r.hit can be left set by a rejected transformed hit only when an
-    // earlier object already hit, so `hit` and r.hit agree here.
-    const double u = r.beta, v = r.gamma, w = 1.0 - u - v;
-    r.gn = normalize(r.gn);
-    r.sn = normalize(r.sn);
-    if (r.kind == RTX_KIND_MESH && r.container >= 0 && r.container < S.n_meshes) {
-        const Mesh& m = S.meshes[r.container];
-        if (m.smooth && m.has_vn && r.tri >= 0) {
-            const double* vn = S.tri_vn + 9 * (size_t)r.tri;
-            V3 n0 = ld3(vn), n1 = ld3(vn + 3), n2 = ld3(vn + 6);
-            V3 sm = normalize(vadd(vadd(sscale(w, n0), sscale(u, n1)), sscale(v, n2)));
-            if (m.xform >= 0) sm = normalize(xf_dir(S.xforms[m.xform].nrm, sm));
-            r.sn = sm;
-            if (dot(r.gn, d) > 0.0) { r.gn = vneg(r.gn); r.sn = vneg(r.sn); }
-            else if (dot(r.sn, r.gn) < 0.0) r.sn = vneg(r.sn);
-        }
+// End of a traversal job: what rayHitsMesh does after bvh->traverse returns
+// (utils.cpp:533-668), including the fields the winning triangle test wrote
+// (utils.cpp:370-381, bvh.cpp:162).  beta and gamma of the winning triangle are recomputed
+// here with the same arithmetic that accepted it (same inputs, same bits).
+RTX_DEV void job_finalize(const Scene& S, Lane& L, V3 o, const RecOut& out) {
+    if (L.btri < 0) return;
+    int mi, xfi, mat, src;
+    job_ids(S, L, mi, xfi, mat, src);
+    const int tri = L.btri;
+    const Tri& T = S.tris[tri];
+    double t, beta, gamma;
+    tri_test(T.a, L.ro, L.rd, INFINITY, S.isect_eps, t, beta, gamma);
+    const V3 a = ld3(T.a), e1 = ld3(T.e1), e2 = ld3(T.e2);
+    const V3 point = vadd(vadd(a, sscale(beta, e1)), sscale(gamma, e2));
+    const V3 gn = ld3(S.tri_gn + 3 * (size_t)tri);
+    out.bary(beta, gamma, T.face, tri);
+    out.kind(RTX_KIND_MESH);
+    if (xfi < 0) {
+        out.geom(L.t_min, point, gn, gn);
+        out.owner(mat, mi);
+        out.src(src);
+        L.dist = L.t_min; L.hit = 1;
+        return;
     }
+    const Xform& xf = S.xforms[xfi];
+    const Mesh& m = S.meshes[mi];
+    V3 wp = xf_point(xf.m, point);
+    double dx = wp.x - o.x, dy = wp.y - o.y, dz = wp.z - o.z;
+    double wd = (double)sqrtf((float)(dx * dx + dy * dy + dz * dz));
+    if (wd >= L.orig_t_min) {             // utils.cpp:567-570: bound restored, record is not
+        out.geom(L.t_min, point, gn, gn);
+        out.owner(mat, mi);
+        L.dist = L.t_min;
+        L.t_min = L.orig_t_min;
+        return;
+    }
+    V3 wg = normalize_f32(xf_dir(xf.nrm, gn));
+    V3 ws;
+    if (m.smooth && m.has_vn) {           // utils.cpp:589-621
+        double u = beta, v = gamma, w = 1.0 - u - v;
+        const double* vn = S.tri_vn + 9 * (size_t)tri;
+        double nx = w * vn[0] + u * vn[3] + v * vn[6];
+        double ny = w * vn[1] + u * vn[4] + v * vn[7];
+        double nz = w * vn[2] + u * vn[5] + v * vn[8];
+        double nlen = (double)sqrtf((float)(nx * nx + ny * ny + nz * nz));
+        double ninv = 1.0 / nlen;
+        nx *= ninv; ny *= ninv; nz *= ninv;
+        ws = xf_dir(xf.nrm, mk(nx, ny, nz));
+    } else {
+        ws = xf_dir(xf.nrm, gn);
+    }
+    {
+        double slen = (double)sqrtf((float)(ws.x * ws.x + ws.y * ws.y + ws.z * ws.z));
+        double sinv = 1.0 / slen;
+        ws.x *= sinv; ws.y *= sinv; ws.z *= sinv;
+    }
+    if (dot(wg, L.d) > 0.0) { wg = vneg(wg); ws = vneg(ws); }
+    out.geom(wd, wp, wg, ws);
+    out.owner(mat, -2);
+    out.src(src);
+    L.dist = wd;
+    L.t_min = wd;
+    L.hit = 1;
 }
 
 // utils.cpp:1089-1111
@@ -713,15 +740,195 @@ RTX_DEV unsigned queue_slot(unsigned w, unsigned n_radiance, unsigned capacity) 
     return w < n_radiance ? w : capacity - 1u - (w - n_radiance);
 }
 
+// Divergent per-lane part of a service pass, kept out of line: the traversal loop then only
+// pays (in registers) for what a traversal step needs, and the hot state is saved around the
+// call.  `fresh`: the lane has just been handed a new ray (L.slot / L.d / L.is_shadow set).
 template <bool COUNT>
-__global__ void __launch_bounds__(256)
-k_trace(const Scene S, const Frame F, const Queue qin, const HitBuf hb, GenCtrl* ctrl, const int gen,
-        double* __restrict__ accum, rtx_hit_id* __restrict__ aov, Counters* __restrict__ counters) {
-    __shared__ __attribute__((aligned(16))) double lds_rows[4][64 * RTX_ROW_DOUBLES];
+__device__ __noinline__ void service_lane(const Launch* __restrict__ Lp, const int gen, double* __restrict__ accum,
+                                          rtx_hit_id* __restrict__ aov, Lane& L, const bool fresh, Tally& tl) {
+    const Scene& S = Lp->S;
+    const Frame& F = Lp->F;
+    const Queue& qin = Lp->q[(gen + 1) & 1];
+    const HitBuf& hb = Lp->hb;
+    const unsigned slot = L.slot;
+    const V3 o = gen == 0 ? ld3(F.e) : mk(qin.ox[slot], qin.oy[slot], qin.oz[slot]);
+    RecOut out;
+    out.hb = hb; out.slot = slot; out.on = L.is_shadow == 0; out.ids = (gen == 0 && aov != nullptr);
+    if (fresh) {
+        if (COUNT) { tl.rays++; if (gen == 0) tl.primary++; else if (L.is_shadow) tl.shadow++; else tl.secondary++; }
+        ray_begin<COUNT>(S, L, o, out, tl);
+    }
+    if (L.state == LS_JOB_DONE) { job_finalize(S, L, o, out); L.state = LS_NEED_JOB; }
+    if (job_next<COUNT>(S, L, o, out, tl)) { L.state = LS_IN_JOB; return; }
+    // ---- ray complete ------------------------------------------------------------------------
+    const bool hit = L.hit != 0;
+    if (L.is_shadow) {                                            // utils.cpp:1083
+        if (!(hit && L.dist < qin.aux[slot]))
+            add_color(accum, qin.pixel[slot], mk(qin.wx[slot], qin.wy[slot], qin.wz[slot]));
+    } else {
+        hb.code[slot] = hit ? 1 : -1;
+        if (gen == 0 && aov != nullptr) {
+            int px, py; unsigned pixel;
+            primary_pixel(F, slot, px, py, pixel);
+            rtx_hit_id h;
+            h.kind = 0; h.container = -1; h.face = -1; h.src = -1; h.distance = 0.0;
+            if (hit) {
+                // read back what this lane stored (bypassing the vector L1)
+                h.kind = __hip_atomic_load(&hb.kind[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                h.container = __hip_atomic_load(&hb.container[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const int face = __hip_atomic_load(&hb.face[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const int src = __hip_atomic_load(&hb.src[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                h.face = (h.kind == RTX_KIND_MESH || h.kind == RTX_KIND_TRIANGLE) ? face : -1;
+                h.src = h.kind == RTX_KIND_MESH ? src : h.container;
+                h.distance = L.dist;
+            }
+            aov[(size_t)py * F.width + px] = h;
+        }
+    }
+    L.state = LS_EMPTY;
+}
+
+// The traversal loop, kept out of line so that its register budget is its own: runs
+// cooperative steps for the lanes that are inside a job until the wave needs a service pass
+// (enough lanes wait for one) or no lane is traversing.  `refillable`: idle lanes could be
+// handed new rays, so they count as waiting for service.
+//
+// In one step every traversing lane advances by one record: a lane at an inner node gets the
+// node (both child boxes) and descends, a lane in a leaf gets the leaf's next triangle and
+// tests it.  Both kinds of record arrive through the same cooperative fetch, so the step has
+// a single exposed memory latency whatever the mix of lanes.
+//
+// Visit order and visited set of bvh.cpp:104-185: children ordered near/far by the sign of
+// dir[splitAxis] (near first); a node is entered iff its box test passes with the bound current
+// when the reference would pop it.  Both children's boxes are evaluated at their parent; the
+// far child is pushed with its entry distance and re-checked against the (possibly smaller)
+// bound when popped -- the predicate the reference evaluates at that moment.
+//
+// Stack entries are 16 bytes (entry distance, ref, count).  The top entry is kept in
+// registers (Lane::top); memory holds the entries below it, so the load a pop issues to refill
+// the top is not needed before the next pop and overlaps the next record fetch.
+template <bool COUNT>
+__device__ __noinline__ void traverse_steps(const Launch* __restrict__ Lp, lds_double* rows, Lane& Lmem,
+                                            priv_v4i* __restrict__ stk, const bool refillable, Tally& tlmem) {
+    const Scene& S = Lp->S;
     Wave wv;
     wv.lane = lane_id();
-    wv.rows = &lds_rows[threadIdx.x >> 6][0];
+    wv.rows = rows;
     const unsigned lane = wv.lane;
+    const char* const nodes = (const char*)S.nodes;
+    const char* const tris = (const char*)S.tris;
+    const double* const tri_gn = S.tri_gn;
+    const bool cull = S.cull != 0;
+    const double isect_eps = S.isect_eps;
+    // hot state in registers for the duration of the call
+    V3 ro = Lmem.ro, rd = Lmem.rd;
+    Slab sl;
+    sl.ox = ro.x; sl.oy = ro.y; sl.oz = ro.z; sl.ix = Lmem.ix; sl.iy = Lmem.iy; sl.iz = Lmem.iz; sl.par = Lmem.par;
+    double t_min = Lmem.t_min;
+    int cur_ref = Lmem.cur_ref, cur_cnt = Lmem.cur_cnt, sp = Lmem.sp, btri = Lmem.btri, state = Lmem.state;
+    v4i top = Lmem.top;
+    unsigned node_visits = 0, tri_tests = 0, inner_steps = 0, inner_lanes = 0, leaf_steps = 0, leaf_lanes = 0;
+    unsigned long long clk_fetch = 0, clk_pop = 0;
+
+    while (true) {
+        const bool in_job = state == LS_IN_JOB;
+        const bool at_leaf = in_job && cur_cnt > 0;
+        const unsigned long long m_job = __ballot(in_job);
+        if (m_job == 0ull) break;
+        const unsigned long long m_wait = __ballot(state == LS_NEED_JOB || state == LS_JOB_DONE ||
+                                                   (refillable && state == LS_EMPTY));
+        if (__popcll(m_wait) >= RTX_SERVICE_THRESHOLD) break;
+        if (COUNT && lane == 0) {
+            const int nl = __popcll(__ballot(at_leaf)), nj = __popcll(m_job);
+            if (nj > nl) { inner_steps++; inner_lanes += (unsigned)(nj - nl); }
+            if (nl) { leaf_steps++; leaf_lanes += (unsigned)nl; }
+        }
+
+        const long long f0 = COUNT ? clock64() : 0;
+        coop_fetch(wv, m_job, at_leaf ? (cur_ref | (int)0x80000000) : cur_ref, nodes, tris);
+        if (COUNT) clk_fetch += (unsigned long long)(clock64() - f0);
+
+        bool need_pop = false;
+        if (in_job) {
+            if (!at_leaf) {
+                if (COUNT) node_visits++;
+                double nd[16];
+                row_read<8>(wv, nd);
+                const int lref = __double2loint(nd[12]), lcnt = __double2hiint(nd[12]);
+                const int rref = __double2loint(nd[13]), rcnt = __double2hiint(nd[13]);
+                const int axis = __double2loint(nd[14]);
+                double el, er;
+                const bool okl = box_enter(nd + 0, nd + 3, sl, el) && (t_min >= el);
+                const bool okr = box_enter(nd + 6, nd + 9, sl, er) && (t_min >= er);
+                const double da = axis == 0 ? rd.x : (axis == 1 ? rd.y : rd.z);
+                const bool left_near = da >= 0.0;
+                const int nref = left_near ? lref : rref, ncnt = left_near ? lcnt : rcnt;
+                const int fref = left_near ? rref : lref, fcnt = left_near ? rcnt : lcnt;
+                const bool okn = left_near ? okl : okr, okf = left_near ? okr : okl;
+                const double ef = left_near ? er : el;
+                if (okn) {
+                    if (okf && sp < RTX_STACK) {
+                        if (sp > 0) stk[sp - 1] = top;
+                        top.x = __double2loint(ef); top.y = __double2hiint(ef); top.z = fref; top.w = fcnt;
+                        sp++;
+                    }
+                    cur_ref = nref; cur_cnt = ncnt;
+                } else if (okf) {
+                    cur_ref = fref; cur_cnt = fcnt;
+                } else {
+                    need_pop = true;
+                }
+            } else {
+                // the leaf's next triangle, in leaf order (bvh.cpp:150-170)
+                const int ti = cur_ref;
+                if (COUNT) tri_tests++;
+                bool culled = false;
+                if (cull) {
+                    const double* g = tri_gn + 3 * (size_t)ti;
+                    culled = rd.x * g[0] + rd.y * g[1] + rd.z * g[2] > 0.0;
+                }
+                double td[10];
+                row_read<5>(wv, td);
+                double t, b, g2;
+                if (!culled && tri_test(td, ro, rd, t_min, isect_eps, t, b, g2)) { t_min = t; btri = ti; }
+                cur_ref++; cur_cnt--;
+                need_pop = cur_cnt == 0;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        const long long p0 = COUNT ? clock64() : 0;
+        if (need_pop) {
+            state = LS_JOB_DONE;
+            while (sp > 0) {
+                const v4i e = top;
+                --sp;
+                if (sp > 0) top = stk[sp - 1];
+                if (t_min >= __hiloint2double(e.y, e.x)) { cur_ref = e.z; cur_cnt = e.w; state = LS_IN_JOB; break; }
+            }
+        }
+        if (COUNT) clk_pop += (unsigned long long)(clock64() - p0);
+    }
+    Lmem.t_min = t_min;
+    Lmem.cur_ref = cur_ref; Lmem.cur_cnt = cur_cnt; Lmem.sp = sp; Lmem.btri = btri; Lmem.state = state;
+    Lmem.top = top;
+    if (COUNT) {
+        tlmem.node_visits += node_visits; tlmem.tri_tests += tri_tests;
+        tlmem.inner_steps += inner_steps; tlmem.inner_lanes += inner_lanes;
+        tlmem.leaf_steps += leaf_steps; tlmem.leaf_lanes += leaf_lanes;
+        tlmem.clk_fetch += clk_fetch; tlmem.clk_pop += clk_pop;
+    }
+}
+
+template <bool COUNT>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RTX_TRACE_WAVES, RTX_TRACE_WAVES)))
+k_trace(const Launch* __restrict__ Lp, GenCtrl* ctrl, const int gen, double* __restrict__ accum,
+        rtx_hit_id* __restrict__ aov, Counters* __restrict__ counters) {
+    const Frame& F = Lp->F;
+    const Queue& qin = Lp->q[(gen + 1) & 1];
+    const HitBuf& hb = Lp->hb;
+    __shared__ __attribute__((aligned(16))) double lds_rows[4][64 * RTX_ROW_DOUBLES];
+    lds_double* rows = (lds_double*)&lds_rows[threadIdx.x >> 6][0];
+    const unsigned lane = lane_id();
     GenCtrl* me = ctrl + gen;
     unsigned n_rad = 0, n_in = 0;
     if (gen == 0) { n_rad = (unsigned)F.n_items0; n_in = n_rad; }
@@ -731,75 +938,90 @@ k_trace(const Scene S, const Frame F, const Queue qin, const HitBuf hb, GenCtrl*
         n_rad = min((unsigned)c, qin.capacity);
         n_in = n_rad + min((unsigned)(c >> 32), qin.capacity - n_rad);
     }
-    Tally tl = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-    unsigned n_rays = 0, n_primary = 0, n_shadow = 0, n_secondary = 0;
+    Tally tl = {};
+    const long long clk_begin = COUNT ? clock64() : 0;
 
-    // Rays claimed per wave and fetch: 64 when the generation can fill the whole grid,
-    // fewer when it cannot -- a thin generation (deep reflection chains) is latency bound,
-    // and spreading its rays over more waves shortens the slowest wave.
-    unsigned batch = 64u;
+    // Rays are claimed in chunks (one atomic per chunk per wave) and handed to lanes as they
+    // fall idle.  A thin generation is latency bound: smaller chunks spread it over more waves.
+    unsigned chunk = RTX_CHUNK;
     if (gen != 0) {
         const unsigned waves = gridDim.x * (blockDim.x >> 6);
-        batch = (n_in + waves - 1u) / waves;
-        batch = batch < 1u ? 1u : (batch > 64u ? 64u : batch);
+        chunk = (n_in + waves - 1u) / waves;
+        chunk = chunk < 1u ? 1u : (chunk > RTX_CHUNK ? RTX_CHUNK : chunk);
     }
+    unsigned chunk_next = 0, chunk_end = 0;      // wave-uniform
+    bool drained = false;                        // wave-uniform: the generation has no rays left
+
+    // The lane state and the traversal stack live in private memory; the two out-of-line
+    // phases load what they need.
+    v4i stk[RTX_STACK];
+    Lane L;
+    L.state = LS_EMPTY; L.cur_cnt = 0; L.cur_ref = 0; L.sp = 0; L.slot = 0; L.is_shadow = 0; L.btri = -1;
+    L.top = (v4i)(0); L.t_min = 0.0; L.ro = mk(0, 0, 0); L.rd = mk(0, 0, 1); L.ix = L.iy = L.iz = 0.0; L.par = 0;
 
     while (true) {
-        unsigned base = 0;
-        if (lane == 0) base = atomicAdd(&me->head_trace, batch);
-        base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
-        if (base >= n_in) break;
-        const unsigned item = base + lane;
-        bool active = lane < batch && item < n_in;
+        const int state = L.state;
+        const unsigned long long m_empty = __ballot(state == LS_EMPTY);
+        const unsigned long long m_need = __ballot(state == LS_NEED_JOB || state == LS_JOB_DONE);
+        const unsigned long long m_trav = __ballot(state == LS_IN_JOB);
+        const int n_service = __popcll(m_need) + (drained ? 0 : __popcll(m_empty));
 
-        V3 o = mk(0, 0, 0), d = mk(0, 0, 1);
-        unsigned slot = item, pixel = 0;
-        int px = 0, py = 0;
-        bool is_shadow = false;
-        if (gen == 0) {
-            active = primary_pixel(F, item, px, py, pixel) && active;
-            if (active) { o = ld3(F.e); d = primary_direction(F, px, py); }
-        } else if (active) {
-            is_shadow = item >= n_rad;
-            slot = queue_slot(item, n_rad, qin.capacity);
-            o = mk(qin.ox[slot], qin.oy[slot], qin.oz[slot]);
-            d = mk(qin.dx[slot], qin.dy[slot], qin.dz[slot]);
-        }
-
-        Rec r;
-        intersect<COUNT>(S, wv, active, o, d, r, tl);
-        if (COUNT && active) { n_rays++; if (gen == 0) n_primary++; else if (is_shadow) n_shadow++; else n_secondary++; }
-        if (!active) continue;
-
-        if (gen == 0 && aov != nullptr) {
-            rtx_hit_id h;
-            h.kind = r.hit ? r.kind : 0;
-            h.container = r.hit ? r.container : -1;
-            h.face = (r.hit && (r.kind == RTX_KIND_MESH || r.kind == RTX_KIND_TRIANGLE)) ? r.face : -1;
-            h.src = r.hit ? (r.kind == RTX_KIND_MESH ? r.src : r.container) : -1;
-            h.distance = r.hit ? r.dist : 0.0;
-            aov[(size_t)py * F.width + px] = h;
-        }
-        if (is_shadow) {                                             // utils.cpp:1083
-            if (!(r.hit && r.dist < qin.aux[slot]))
-                add_color(accum, qin.pixel[slot], mk(qin.wx[slot], qin.wy[slot], qin.wz[slot]));
-        } else {
-            hb.code[slot] = r.hit ? r.mat + 1 : -1;
-            if (r.hit) {
-                hb.dist[slot] = r.dist;
-                hb.px[slot] = r.point.x; hb.py[slot] = r.point.y; hb.pz[slot] = r.point.z;
-                hb.gx[slot] = r.gn.x; hb.gy[slot] = r.gn.y; hb.gz[slot] = r.gn.z;
-                hb.sx[slot] = r.sn.x; hb.sy[slot] = r.sn.y; hb.sz[slot] = r.sn.z;
+        if (n_service > 0 && (m_trav == 0ull || n_service >= RTX_SERVICE_THRESHOLD)) {
+            // ---- service pass ---------------------------------------------------------------
+            const long long c0 = COUNT ? clock64() : 0;
+            for (int rep = 0; rep < 4; rep++) {
+                const unsigned long long me_ = __ballot(L.state == LS_EMPTY);
+                bool fresh = false;
+                if (me_ != 0ull && !drained) {
+                    if (chunk_next == chunk_end) {
+                        unsigned base = 0;
+                        if (lane == 0) base = atomicAdd(&me->head_trace, chunk);
+                        base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
+                        if (base >= n_in) { drained = true; chunk_next = chunk_end = 0; }
+                        else { chunk_next = base; chunk_end = min(base + chunk, n_in); }
+                    }
+                    if (!drained) {
+                        const unsigned take = min((unsigned)__popcll(me_), chunk_end - chunk_next);
+                        const unsigned rank = (unsigned)__popcll(me_ & ((1ull << lane) - 1ull));
+                        if (L.state == LS_EMPTY && rank < take) {
+                            const unsigned item = chunk_next + rank;
+                            if (gen == 0) {
+                                int px, py; unsigned pixel;
+                                L.slot = item; L.is_shadow = 0;
+                                if (primary_pixel(F, item, px, py, pixel)) { L.d = primary_direction(F, px, py); fresh = true; }
+                                else hb.code[item] = -2;               // padding item outside the image
+                            } else {
+                                L.is_shadow = item >= n_rad ? 1 : 0;
+                                L.slot = queue_slot(item, n_rad, qin.capacity);
+                                L.d = mk(qin.dx[L.slot], qin.dy[L.slot], qin.dz[L.slot]);
+                                fresh = true;
+                            }
+                        }
+                        chunk_next += take;
+                    }
+                }
+                if (fresh || L.state == LS_JOB_DONE || L.state == LS_NEED_JOB)
+                    service_lane<COUNT>(Lp, gen, accum, aov, L, fresh, tl);
+                if (drained || __ballot(L.state == LS_EMPTY) == 0ull) break;
             }
+            if (COUNT) { tl.clk_serv += (unsigned long long)(clock64() - c0); tl.passes++; }
+            continue;
         }
+        if (m_trav == 0ull) break;
+        const long long c1 = COUNT ? clock64() : 0;
+        traverse_steps<COUNT>(Lp, rows, L, (priv_v4i*)stk, !drained, tl);
+        if (COUNT) tl.clk_trav += (unsigned long long)(clock64() - c1);
     }
 
     if (COUNT && counters) {
-        unsigned long long v[13] = {n_rays, n_primary, n_shadow, n_secondary, tl.node_visits, tl.tri_tests,
+        const bool l0 = lane == 0;
+        unsigned long long v[20] = {tl.rays, tl.primary, tl.shadow, tl.secondary, tl.node_visits, tl.tri_tests,
                                     tl.world_box, tl.obj_trav, tl.tlas_visits, tl.inner_steps, tl.inner_lanes,
-                                    tl.leaf_steps, tl.leaf_lanes};
+                                    tl.leaf_steps, tl.leaf_lanes, l0 ? tl.passes : 0u, l0 ? tl.clk_trav : 0ull,
+                                    l0 ? tl.clk_serv : 0ull, l0 ? (unsigned long long)(clock64() - clk_begin) : 0ull,
+                                    l0 ? 1ull : 0ull, l0 ? tl.clk_fetch : 0ull, l0 ? tl.clk_pop : 0ull};
 #pragma unroll
-        for (int k = 0; k < 13; k++) {
+        for (int k = 0; k < 20; k++) {
             unsigned long long x = v[k];
             for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off);
             if (lane == 0 && x) atomicAdd(((unsigned long long*)counters) + k, x);
@@ -810,8 +1032,12 @@ k_trace(const Scene S, const Frame F, const Queue qin, const HitBuf hb, GenCtrl*
 // Shading of the radiance hits of one generation (utils.cpp:868-1061) and emission of the
 // next generation's rays.
 __global__ void __launch_bounds__(256)
-k_shade(const Scene S, const Frame F, const Queue qin, const Queue qout, const HitBuf hb, GenCtrl* ctrl,
-        const int gen, double* __restrict__ accum) {
+k_shade(const Launch* __restrict__ Lp, GenCtrl* ctrl, const int gen, double* __restrict__ accum) {
+    const Scene& S = Lp->S;
+    const Frame& F = Lp->F;
+    const Queue& qin = Lp->q[(gen + 1) & 1];
+    const Queue& qout = Lp->q[gen & 1];
+    const HitBuf& hb = Lp->hb;
     const unsigned lane = lane_id();
     GenCtrl* me = ctrl + gen;
     GenCtrl* next = ctrl + gen + 1;
@@ -846,19 +1072,39 @@ k_shade(const Scene S, const Frame F, const Queue qin, const Queue qout, const H
         if (active) {
             const int code = hb.code[slot];
             if (code < 0) {
-                if (depth == 0) add_color(accum, pixel, vmul(W, ld3(S.bg)));      // utils.cpp:1055-1058
+                if (depth == 0 && code == -1) add_color(accum, pixel, vmul(W, ld3(S.bg)));      // utils.cpp:1055-1058
             } else {
+                mat = hb.mat[slot];
                 if (beer >= 0) {                                                     // utils.cpp:975-984
                     const Material& pm = S.materials[beer];
                     V3 ab = vscale(ld3(pm.sigma), hb.dist[slot]);
                     W = vmul(W, mk(exp(-ab.x), exp(-ab.y), exp(-ab.z)));
                 }
-                mat = code - 1;
                 if (mat >= 0) {
                     shade = true;
                     P = mk(hb.px[slot], hb.py[slot], hb.pz[slot]);
-                    gn = mk(hb.gx[slot], hb.gy[slot], hb.gz[slot]);
-                    sn = mk(hb.sx[slot], hb.sy[slot], hb.sz[slot]);
+                    // tail of intersect(), utils.cpp:807-853: normalise both normals; for an
+                    // untransformed smooth mesh (or a record a rejected transformed hit left
+                    // behind) interpolate the vertex normals and face them against the ray
+                    gn = normalize(mk(hb.gx[slot], hb.gy[slot], hb.gz[slot]));
+                    sn = normalize(mk(hb.sx[slot], hb.sy[slot], hb.sz[slot]));
+                    const int cont = hb.container[slot];
+                    int ptri = -1;
+                    if (hb.kind[slot] == RTX_KIND_MESH && cont >= 0 && cont < S.n_meshes) {
+                        const Mesh& cm = S.meshes[cont];
+                        if (cm.smooth && cm.has_vn) ptri = hb.tri[slot];
+                    }
+                    if (ptri >= 0) {
+                        const double u = hb.beta[slot], v = hb.gamma[slot], w = 1.0 - u - v;
+                        const Mesh& pm = S.meshes[cont];
+                        const double* vn = S.tri_vn + 9 * (size_t)ptri;
+                        V3 n0 = ld3(vn), n1 = ld3(vn + 3), n2 = ld3(vn + 6);
+                        V3 sm = normalize(vadd(vadd(sscale(w, n0), sscale(u, n1)), sscale(v, n2)));
+                        if (pm.xform >= 0) sm = normalize(xf_dir(S.xforms[pm.xform].nrm, sm));
+                        sn = sm;
+                        if (dot(gn, d) > 0.0) { gn = vneg(gn); sn = vneg(sn); }
+                        else if (dot(sn, gn) < 0.0) sn = vneg(sn);
+                    }
                 }
             }
         }
