@@ -72,7 +72,7 @@ struct rtx_scene {
     uint32_t queue_capacity = 0;    // rays per queue, grows on overflow and is then kept
     DevBuf materials, lights, xforms, planes, spheres, ftris, meshes, insts, nodes, tris, tri_gn, tri_vn,
         tlas, tlas_order;
-    DevBuf accum, rgb, aov, ctrl, counters, queue[2], hitbuf, launch;
+    DevBuf accum, rgb, aov, ctrl, counters, queue[2], hitbuf, launch, stacks;
     ~rtx_scene() {
         if (ev0) (void)hipEventDestroy(ev0);
         if (ev1) (void)hipEventDestroy(ev1);
@@ -569,7 +569,9 @@ int rtx_render(rtx_scene* sc, const rtx_camera* cam, int32_t tw, int32_t th, int
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, sc->device) == hipSuccess && prop.multiProcessorCount > 0) dev_cus = prop.multiProcessorCount;
     }
-    const unsigned persistent_blocks = (unsigned)dev_cus * 8u;
+    // One grid of resident blocks: RTX_TRACE_WAVES waves per SIMD = that many 256-thread blocks per CU.
+    const unsigned persistent_blocks = (unsigned)dev_cus * (unsigned)RTX_TRACE_WAVES;
+    HIP_TRY(sc->stacks.ensure((size_t)persistent_blocks * 256u * RTX_STACK * 16u));
 
     if (sc->queue_capacity == 0) {
         int64_t want = std::max<int64_t>(n_local_px * (int64_t)(sc->dev.n_lights + 2), 1 << 16);
@@ -593,6 +595,7 @@ int rtx_render(rtx_scene* sc, const rtx_camera* cam, int32_t tw, int32_t th, int
         launch.q[0] = make_queue(sc->queue[0].p, sc->queue_capacity);
         launch.q[1] = make_queue(sc->queue[1].p, sc->queue_capacity);
         launch.hb = make_hitbuf(sc->hitbuf.p, hit_cap);
+        launch.stacks = sc->stacks.p;
         HIP_TRY(sc->launch.ensure(sizeof(Launch)));
         // pageable source: the copy is staged before the call returns, so `launch` may go out of scope
         HIP_TRY(hipMemcpyAsync(sc->launch.p, &launch, sizeof launch, hipMemcpyHostToDevice, sc->stream));
@@ -683,6 +686,12 @@ int rtx_render(rtx_scene* sc, const rtx_camera* cam, int32_t tw, int32_t th, int
                 (double)ctr.clk_traverse / std::max(1ull, ctr.inner_steps + ctr.leaf_steps),
                 (double)ctr.clk_fetch / std::max(1ull, ctr.inner_steps + ctr.leaf_steps),
                 (double)ctr.clk_pop / std::max(1ull, ctr.inner_steps + ctr.leaf_steps));
+    if (sc->counters_on && getenv("RTX_AMD_GEN_TIMING")) {
+        static const char* names[4] = {"begin", "finalize", "next-job", "complete"};
+        for (int k = 0; k < 4; k++)
+            fprintf(stderr, "[rtx]   service %-9s %10llu lane-calls, %8.0f ticks each\n", names[k], ctr.section[4 + k],
+                    (double)ctr.section[k] / std::max(1ull, ctr.section[4 + k]));
+    }
     if (stats) {
         stats->rays = ctr.rays; stats->primary_rays = ctr.primary; stats->shadow_rays = ctr.shadow;
         stats->secondary_rays = ctr.secondary; stats->node_visits = ctr.node_visits; stats->tri_tests = ctr.tri_tests;

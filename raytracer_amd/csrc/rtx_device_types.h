@@ -151,6 +151,10 @@ struct Launch {
     Frame F;
     Queue q[2];
     HitBuf hb;
+    // Traversal stacks of the trace kernel: RTX_STACK 16-byte entries per lane, each lane's
+    // entries contiguous (a push or pop touches one cache line per lane), indexed by
+    // (global wave number * 64 + lane).
+    void* stacks;
 };
 
 struct Counters {
@@ -159,6 +163,7 @@ struct Counters {
     unsigned long long inner_steps, inner_lanes, leaf_steps, leaf_lanes;
     // time split of the trace kernel's waves, in shader-clock ticks summed over waves
     unsigned long long service_passes, clk_traverse, clk_service, clk_total, waves, clk_fetch, clk_pop;
+    unsigned long long section[8];   // service sections: ticks summed over lanes (begin, finalize, next job, complete), then call counts
 };
 
 }  // namespace rtxdev

@@ -170,7 +170,8 @@ struct Tally { unsigned node_visits, tri_tests, world_box, obj_trav, tlas_visits
                unsigned inner_steps, inner_lanes, leaf_steps, leaf_lanes;       // wave-step occupancy (lane 0 only)
                unsigned rays, primary, shadow, secondary;
                unsigned passes;                                                  // service passes (lane 0)
-               unsigned long long clk_trav, clk_serv, clk_total, clk_fetch, clk_pop; };              // shader-clock ticks (lane 0)
+               unsigned long long clk_trav, clk_serv, clk_total, clk_fetch, clk_pop;
+               unsigned long long sec[8]; };   // per-lane section profile of service_lane: ticks (0-3), calls (4-7)              // shader-clock ticks (lane 0)
 
 #define RTX_STACK 64
 #define RTX_ROW_DOUBLES 16          // one 128-byte LDS row per lane
@@ -184,7 +185,7 @@ typedef __attribute__((address_space(3))) double lds_double;
 typedef double v2d __attribute__((ext_vector_type(2)));
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) v2d lds_v2d;
-typedef __attribute__((address_space(5))) v4i priv_v4i;
+typedef __attribute__((address_space(1))) v4i glob_v4i;
 
 // Per-wave context: this wave's 64 LDS rows and the lane number.
 struct Wave { lds_double* rows; unsigned lane; };
@@ -201,12 +202,16 @@ struct Wave { lds_double* rows; unsigned lane; };
 RTX_DEV void coop_fetch(const Wave& wv, unsigned long long mask, int key, const char* __restrict__ nodes,
                         const char* __restrict__ tris) {
     const unsigned sub = wv.lane >> 3, slot = wv.lane & 7u;
+    // all eight cross-lane reads first, so that their latencies overlap
+    int okeys[8];
+#pragma unroll
+    for (int g = 0; g < 8; g++) okeys[g] = __shfl(key, 8 * g + (int)sub);
 #pragma unroll
     for (int g = 0; g < 8; g++) {
         const unsigned gm = (unsigned)(mask >> (8 * g)) & 0xFFu;        // wave-uniform
         if (gm) {
             const int owner = 8 * g + (int)sub;
-            const int okey = __shfl(key, owner);
+            const int okey = okeys[g];
             const unsigned piece = slot ^ (((unsigned)owner >> 1) & 7u);
             const bool is_tri = okey < 0;
             if (((gm >> sub) & 1u) && (!is_tri || piece < 5u)) {
@@ -218,7 +223,10 @@ RTX_DEV void coop_fetch(const Wave& wv, unsigned long long mask, int key, const 
             }
         }
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // vmcnt(0), as a builtin rather than inline assembly so that the compiler's own wait-count
+    // bookkeeping knows that nothing is outstanding after it (gfx9 encoding: vmcnt bits 3:0 and
+    // 15:14 zero, expcnt 6:4 and lgkmcnt 11:8 left at "no wait")
+    __builtin_amdgcn_s_waitcnt(0x0F70);
     __builtin_amdgcn_wave_barrier();
 }
 
@@ -754,12 +762,19 @@ __device__ __noinline__ void service_lane(const Launch* __restrict__ Lp, const i
     const V3 o = gen == 0 ? ld3(F.e) : mk(qin.ox[slot], qin.oy[slot], qin.oz[slot]);
     RecOut out;
     out.hb = hb; out.slot = slot; out.on = L.is_shadow == 0; out.ids = (gen == 0 && aov != nullptr);
+    long long c0 = COUNT ? clock64() : 0;
     if (fresh) {
         if (COUNT) { tl.rays++; if (gen == 0) tl.primary++; else if (L.is_shadow) tl.shadow++; else tl.secondary++; }
         ray_begin<COUNT>(S, L, o, out, tl);
+        if (COUNT) { const long long c = clock64(); tl.sec[0] += (unsigned long long)(c - c0); tl.sec[4]++; c0 = c; }
     }
-    if (L.state == LS_JOB_DONE) { job_finalize(S, L, o, out); L.state = LS_NEED_JOB; }
-    if (job_next<COUNT>(S, L, o, out, tl)) { L.state = LS_IN_JOB; return; }
+    if (L.state == LS_JOB_DONE) {
+        job_finalize(S, L, o, out); L.state = LS_NEED_JOB;
+        if (COUNT) { const long long c = clock64(); tl.sec[1] += (unsigned long long)(c - c0); tl.sec[5]++; c0 = c; }
+    }
+    const bool more = job_next<COUNT>(S, L, o, out, tl);
+    if (COUNT) { const long long c = clock64(); tl.sec[2] += (unsigned long long)(c - c0); tl.sec[6]++; c0 = c; }
+    if (more) { L.state = LS_IN_JOB; return; }
     // ---- ray complete ------------------------------------------------------------------------
     const bool hit = L.hit != 0;
     if (L.is_shadow) {                                            // utils.cpp:1083
@@ -786,6 +801,7 @@ __device__ __noinline__ void service_lane(const Launch* __restrict__ Lp, const i
         }
     }
     L.state = LS_EMPTY;
+    if (COUNT) { tl.sec[3] += (unsigned long long)(clock64() - c0); tl.sec[7]++; }
 }
 
 // The traversal loop, kept out of line so that its register budget is its own: runs
@@ -804,12 +820,14 @@ __device__ __noinline__ void service_lane(const Launch* __restrict__ Lp, const i
 // far child is pushed with its entry distance and re-checked against the (possibly smaller)
 // bound when popped -- the predicate the reference evaluates at that moment.
 //
-// Stack entries are 16 bytes (entry distance, ref, count).  The top entry is kept in
+// Stack entries are 16 bytes (entry distance, ref, count) in a per-lane region of global
+// memory (private "scratch" arrays interleave lanes dword by dword, which makes a 16-byte
+// access at lane-varying depth touch four cache lines per lane).  The top entry is kept in
 // registers (Lane::top); memory holds the entries below it, so the load a pop issues to refill
 // the top is not needed before the next pop and overlaps the next record fetch.
 template <bool COUNT>
 __device__ __noinline__ void traverse_steps(const Launch* __restrict__ Lp, lds_double* rows, Lane& Lmem,
-                                            priv_v4i* __restrict__ stk, const bool refillable, Tally& tlmem) {
+                                            glob_v4i* __restrict__ stk, const bool refillable, Tally& tlmem) {
     const Scene& S = Lp->S;
     Wave wv;
     wv.lane = lane_id();
@@ -899,11 +917,26 @@ __device__ __noinline__ void traverse_steps(const Launch* __restrict__ Lp, lds_d
         const long long p0 = COUNT ? clock64() : 0;
         if (need_pop) {
             state = LS_JOB_DONE;
-            while (sp > 0) {
-                const v4i e = top;
+            if (sp > 0) {
+                // First pop peeled off the loop: it consumes only registers, and the refill load
+                // it issues stays in flight (inside the loop every iteration has to wait for the
+                // previous iteration's refill).
+                // (everything that reads the old top comes before the load, so the load can
+                // target the registers that hold it)
+                int pass = t_min >= __hiloint2double(top.y, top.x) ? 1 : 0;
+                if (pass) { cur_ref = top.z; cur_cnt = top.w; state = LS_IN_JOB; }
+                asm volatile("" : "+v"(pass), "+v"(cur_ref), "+v"(cur_cnt), "+v"(state));   // old top is dead from here
                 --sp;
-                if (sp > 0) top = stk[sp - 1];
-                if (t_min >= __hiloint2double(e.y, e.x)) { cur_ref = e.z; cur_cnt = e.w; state = LS_IN_JOB; break; }
+                top = stk[sp > 0 ? sp - 1 : 0];          // (entry 0 is always readable)
+                if (!pass) {
+                    while (sp > 0) {
+                        pass = t_min >= __hiloint2double(top.y, top.x);
+                        if (pass) { cur_ref = top.z; cur_cnt = top.w; state = LS_IN_JOB; }
+                        --sp;
+                        if (sp > 0) top = stk[sp - 1];
+                        if (pass) break;
+                    }
+                }
             }
         }
         if (COUNT) clk_pop += (unsigned long long)(clock64() - p0);
@@ -954,7 +987,8 @@ k_trace(const Launch* __restrict__ Lp, GenCtrl* ctrl, const int gen, double* __r
 
     // The lane state and the traversal stack live in private memory; the two out-of-line
     // phases load what they need.
-    v4i stk[RTX_STACK];
+    glob_v4i* const stk = (glob_v4i*)Lp->stacks +
+                          ((size_t)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 64u + lane) * RTX_STACK;
     Lane L;
     L.state = LS_EMPTY; L.cur_cnt = 0; L.cur_ref = 0; L.sp = 0; L.slot = 0; L.is_shadow = 0; L.btri = -1;
     L.top = (v4i)(0); L.t_min = 0.0; L.ro = mk(0, 0, 0); L.rd = mk(0, 0, 1); L.ix = L.iy = L.iz = 0.0; L.par = 0;
@@ -1009,19 +1043,20 @@ k_trace(const Launch* __restrict__ Lp, GenCtrl* ctrl, const int gen, double* __r
         }
         if (m_trav == 0ull) break;
         const long long c1 = COUNT ? clock64() : 0;
-        traverse_steps<COUNT>(Lp, rows, L, (priv_v4i*)stk, !drained, tl);
+        traverse_steps<COUNT>(Lp, rows, L, stk, !drained, tl);
         if (COUNT) tl.clk_trav += (unsigned long long)(clock64() - c1);
     }
 
     if (COUNT && counters) {
         const bool l0 = lane == 0;
-        unsigned long long v[20] = {tl.rays, tl.primary, tl.shadow, tl.secondary, tl.node_visits, tl.tri_tests,
+        unsigned long long v[28] = {tl.rays, tl.primary, tl.shadow, tl.secondary, tl.node_visits, tl.tri_tests,
                                     tl.world_box, tl.obj_trav, tl.tlas_visits, tl.inner_steps, tl.inner_lanes,
                                     tl.leaf_steps, tl.leaf_lanes, l0 ? tl.passes : 0u, l0 ? tl.clk_trav : 0ull,
                                     l0 ? tl.clk_serv : 0ull, l0 ? (unsigned long long)(clock64() - clk_begin) : 0ull,
-                                    l0 ? 1ull : 0ull, l0 ? tl.clk_fetch : 0ull, l0 ? tl.clk_pop : 0ull};
+                                    l0 ? 1ull : 0ull, l0 ? tl.clk_fetch : 0ull, l0 ? tl.clk_pop : 0ull,
+                                    tl.sec[0], tl.sec[1], tl.sec[2], tl.sec[3], tl.sec[4], tl.sec[5], tl.sec[6], tl.sec[7]};
 #pragma unroll
-        for (int k = 0; k < 20; k++) {
+        for (int k = 0; k < 28; k++) {
             unsigned long long x = v[k];
             for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off);
             if (lane == 0 && x) atomicAdd(((unsigned long long*)counters) + k, x);
