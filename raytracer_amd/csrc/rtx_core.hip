@@ -70,7 +70,7 @@ struct rtx_scene {
     bool counters_on = false;
     int64_t queue_limit = (int64_t)32 << 30;
     uint32_t queue_capacity = 0;    // rays per queue, grows on overflow and is then kept
-    DevBuf materials, lights, xforms, planes, spheres, ftris, meshes, insts, nodes, tris, tri_gn, tri_vn,
+    DevBuf materials, lights, xforms, planes, spheres, ftris, meshes, insts, objs, nodes, tris, tri_vn,
         tlas, tlas_order;
     DevBuf accum, rgb, aov, ctrl, counters, queue[2], hitbuf, launch, stacks;
     ~rtx_scene() {
@@ -86,7 +86,7 @@ namespace {
 struct Flat {
     std::vector<Node> nodes;
     std::vector<Tri> tris;
-    std::vector<double> tri_gn, tri_vn;
+    std::vector<double> tri_vn;         // RTX_VN_STRIDE doubles per triangle
     std::vector<Mesh> meshes;
     bool any_vn = false;
 };
@@ -100,20 +100,23 @@ int push_tri(const rtx_scene_desc& d, const rtx_mesh& m, int face, Flat& F) {
     const double* b = d.vertices + 3 * (size_t)f[1];
     const double* c = d.vertices + 3 * (size_t)f[2];
     Tri t;
+    memset(&t, 0, sizeof t);
     for (int k = 0; k < 3; k++) { t.a[k] = a[k]; t.e1[k] = b[k] - a[k]; t.e2[k] = c[k] - a[k]; }
-    t.face = face; t.pad = 0;
-    F.tris.push_back(t);
+    t.face = face;
     // geometricNormal = normalize(crossProduct(e1, e2)), utils.cpp:319-321
     double nx = t.e1[1] * t.e2[2] - t.e1[2] * t.e2[1];
     double ny = t.e1[2] * t.e2[0] - t.e1[0] * t.e2[2];
     double nz = t.e1[0] * t.e2[1] - t.e1[1] * t.e2[0];
     double len = std::sqrt(nx * nx + ny * ny + nz * nz);
-    F.tri_gn.push_back(nx / len); F.tri_gn.push_back(ny / len); F.tri_gn.push_back(nz / len);
-    if (m.smooth && m.vertex_normals)
+    t.gn[0] = nx / len; t.gn[1] = ny / len; t.gn[2] = nz / len;
+    F.tris.push_back(t);
+    if (m.smooth && m.vertex_normals) {
         for (int k = 0; k < 3; k++)
             for (int q = 0; q < 3; q++) F.tri_vn.push_back(m.vertex_normals[3 * (size_t)f[k] + q]);
-    else
-        for (int q = 0; q < 9; q++) F.tri_vn.push_back(0.0);
+        for (int q = 9; q < RTX_VN_STRIDE; q++) F.tri_vn.push_back(0.0);
+    } else {
+        for (int q = 0; q < RTX_VN_STRIDE; q++) F.tri_vn.push_back(0.0);
+    }
     return RTX_OK;
 }
 
@@ -365,6 +368,30 @@ int build_scene(rtx_scene& sc, const rtx_scene_desc& d) {
         S.n_insts = d.n_instances;
     }
 
+    // per-object records: meshes first, then instances
+    std::vector<Obj> objs((size_t)d.n_meshes + (size_t)d.n_instances);
+    auto fill_obj = [&](Obj& o, int mesh, int xform, int material) {
+        memset(&o, 0, sizeof o);
+        o.mesh = mesh; o.material = material; o.flags = OBJ_SKIP;
+        if (mesh < 0) return;
+        const Mesh& bm = F.meshes[(size_t)mesh];
+        memcpy(o.rmin, bm.rmin, 24); memcpy(o.rmax, bm.rmax, 24);
+        o.root_ref = bm.root_ref; o.root_count = bm.root_count;
+        o.flags = bm.n_faces > 0 ? 0 : OBJ_SKIP;
+        if (bm.smooth && bm.has_vn) o.flags |= OBJ_SMOOTH_VN;
+        if (xform >= 0) {
+            const Xform& x = xfs[(size_t)xform];
+            o.flags |= OBJ_XF;
+            if (x.has_bounds) o.flags |= OBJ_BOUNDS;
+            memcpy(o.inv, x.inv, 128); memcpy(o.m, x.m, 128); memcpy(o.nrm, x.nrm, 96);
+            memcpy(o.bmin, x.bmin, 24); memcpy(o.bmax, x.bmax, 24);
+        }
+    };
+    for (int i = 0; i < d.n_meshes; i++) fill_obj(objs[(size_t)i], i, F.meshes[(size_t)i].xform, F.meshes[(size_t)i].material);
+    for (int i = 0; i < d.n_instances; i++)
+        fill_obj(objs[(size_t)d.n_meshes + (size_t)i], insts[(size_t)i].base_mesh, insts[(size_t)i].xform, insts[(size_t)i].material);
+    HIP_TRY(sc.objs.upload(objs));        S.objs = (const Obj*)sc.objs.p;
+
     HIP_TRY(sc.materials.upload(mats));   S.materials = (const Material*)sc.materials.p;
     HIP_TRY(sc.lights.upload(lights));    S.lights = (const Light*)sc.lights.p;
     HIP_TRY(sc.xforms.upload(xfs));       S.xforms = (const Xform*)sc.xforms.p;
@@ -375,7 +402,6 @@ int build_scene(rtx_scene& sc, const rtx_scene_desc& d) {
     HIP_TRY(sc.insts.upload(insts));      S.insts = (const Inst*)sc.insts.p;
     HIP_TRY(sc.nodes.upload(F.nodes));    S.nodes = (const Node*)sc.nodes.p;
     HIP_TRY(sc.tris.upload(F.tris));      S.tris = (const Tri*)sc.tris.p;
-    HIP_TRY(sc.tri_gn.upload(F.tri_gn));  S.tri_gn = (const double*)sc.tri_gn.p;
     if (F.any_vn) { HIP_TRY(sc.tri_vn.upload(F.tri_vn)); S.tri_vn = (const double*)sc.tri_vn.p; }
     else {
         // no smooth mesh: keep has_vn = 0 everywhere, nothing to upload
@@ -400,30 +426,15 @@ int tile_geometry(const rtx_camera* cam, int tw, int th, int first, int stride, 
 
 Queue make_queue(void* base, uint32_t cap) {
     Queue q;
-    char* p = (char*)base;
-    auto take = [&](size_t elem) { void* r = p; p += (size_t)cap * elem; return r; };
-    q.ox = (double*)take(8); q.oy = (double*)take(8); q.oz = (double*)take(8);
-    q.dx = (double*)take(8); q.dy = (double*)take(8); q.dz = (double*)take(8);
-    q.wx = (double*)take(8); q.wy = (double*)take(8); q.wz = (double*)take(8);
-    q.aux = (double*)take(8);
-    q.pixel = (uint32_t*)take(4); q.meta = (uint32_t*)take(4);
-    q.capacity = cap;
+    q.rays = (Ray*)base; q.capacity = cap; q.pad = 0;
     return q;
 }
-constexpr size_t kRayBytes = 10 * 8 + 2 * 4;
-constexpr size_t kHitBytes = 12 * 8 + 7 * 4;
+constexpr size_t kRayBytes = sizeof(Ray);
+constexpr size_t kHitBytes = sizeof(Hit);
 
-HitBuf make_hitbuf(void* base, size_t cap) {
+HitBuf make_hitbuf(void* base, size_t) {
     HitBuf h;
-    char* p = (char*)base;
-    auto take = [&](size_t elem) { void* r = p; p += cap * elem; return r; };
-    h.dist = (double*)take(8);
-    h.px = (double*)take(8); h.py = (double*)take(8); h.pz = (double*)take(8);
-    h.gx = (double*)take(8); h.gy = (double*)take(8); h.gz = (double*)take(8);
-    h.sx = (double*)take(8); h.sy = (double*)take(8); h.sz = (double*)take(8);
-    h.beta = (double*)take(8); h.gamma = (double*)take(8);
-    h.code = (int32_t*)take(4); h.mat = (int32_t*)take(4); h.kind = (int32_t*)take(4);
-    h.container = (int32_t*)take(4); h.face = (int32_t*)take(4); h.tri = (int32_t*)take(4); h.src = (int32_t*)take(4);
+    h.recs = (Hit*)base;
     return h;
 }
 

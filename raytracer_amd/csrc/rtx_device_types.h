@@ -26,10 +26,13 @@ struct Node {
 };
 static_assert(sizeof(Node) == 128, "Node must be 128 bytes");
 
-// Hot triangle record: vertex a and the two edges (b - a), (c - a), plus the original face
-// index; padded to 80 bytes so that records start on 16-byte boundaries (five 16-byte pieces).
-struct Tri { double a[3], e1[3], e2[3]; int32_t face, pad; };
-static_assert(sizeof(Tri) == 80, "Tri must be 80 bytes");
+// Triangle record, 128 bytes = eight 16-byte pieces.  Pieces 0-4 are what a traversal step
+// needs (vertex a, the edges b - a and c - a, the original face index); pieces 5-6 hold the
+// geometric normal normalize((b-a) x (c-a)), needed by back-face culling and when a hit is
+// finalised, so that neither needs a second array.
+struct alignas(16) Tri { double a[3], e1[3], e2[3]; int32_t face, pad; double gn[3]; double pad2[3]; };
+static_assert(sizeof(Tri) == 128, "Tri must be 128 bytes");
+#define RTX_VN_STRIDE 10      // doubles per triangle in tri_vn (9 used; keeps records 16-byte aligned)
 
 struct Mesh {
     double rmin[3], rmax[3];     // root box (tested before anything else, bvh.cpp:132 on node 0)
@@ -51,6 +54,24 @@ struct Inst {
     int32_t xform;        // effective transform: the instance's own, else the base mesh's, else -1
     int32_t pad;
 };
+
+// Everything the trace kernel needs about one traversable object -- mesh i is object i,
+// instance j is object n_meshes + j -- gathered into one record so that setting up or
+// finishing a traversal job is a few wide loads from one place instead of a chain of
+// dependent lookups (instance -> mesh -> transform).  First 256 bytes: job set-up
+// (utils.cpp:418-494); second 256 bytes: what a found hit needs (utils.cpp:533-668).
+enum { OBJ_XF = 1, OBJ_BOUNDS = 2, OBJ_SKIP = 4, OBJ_SMOOTH_VN = 8 };
+struct alignas(16) Obj {
+    double inv[16];                              // world -> object (Object::inverseTransformation)
+    double bmin[3], bmax[3];                     // world-space AABB (valid with OBJ_BOUNDS)
+    double rmin[3], rmax[3];                     // root box of the mesh's BVH (object space)
+    int32_t root_ref, root_count, flags, mesh;   // mesh: index of the (base) mesh
+    int32_t material, pad0[3];
+    double m[16];                                // object -> world
+    double nrm[12];                              // rows 0-2 of the normal matrix
+    int32_t pad1[8];
+};
+static_assert(sizeof(Obj) == 512, "Obj must be 512 bytes");
 
 struct Plane  { double n[3], a[3]; int32_t material, xform; };
 struct Sphere { double c[3], r;    int32_t material, xform; };
@@ -86,10 +107,10 @@ struct Scene {
     const FreeTri* ftris;
     const Mesh* meshes;
     const Inst* insts;
+    const Obj* objs;          // n_meshes + n_insts records
     const Node* nodes;
     const Tri* tris;
-    const double* tri_gn;     // 3 per triangle: normalize((b-a) x (c-a))
-    const double* tri_vn;     // 9 per triangle (vertex normals of its corners) or null
+    const double* tri_vn;     // RTX_VN_STRIDE per triangle (vertex normals of its corners) or null
     const TlasNode* tlas;
     const int32_t* tlas_order;
     // TLAS root (may itself be a leaf)
@@ -106,33 +127,28 @@ struct Frame {
     int32_t n_items0;       // generation-0 work items: selected tiles x 8x8 blocks x 64
 };
 
-// Ray queue (structure of arrays).  Radiance rays occupy slots 0, 1, ... and shadow rays
-// slots capacity-1, capacity-2, ...; meta = depth | (beer_material + 1) << 8.
-struct Queue {
-    double* ox; double* oy; double* oz;
-    double* dx; double* dy; double* dz;
-    double* wx; double* wy; double* wz;
-    double* aux;            // shadow rays: distance to the light
-    uint32_t* pixel;
-    uint32_t* meta;
-    uint32_t capacity;
-};
+// One queued ray, 96 bytes = six 16-byte pieces.  meta = depth | (beer_material + 1) << 8;
+// aux = distance to the light (shadow rays).
+struct alignas(16) Ray { double o[3], d[3], w[3], aux; uint32_t pixel, meta; double pad; };
+static_assert(sizeof(Ray) == 96, "Ray must be 96 bytes");
 
-// Closest-hit records of the radiance rays of one generation (structure of arrays, indexed
-// by queue slot; by work item for generation 0).  During traversal the slot IS the ray's
-// Intersection record (scene.h:248-264): every event that writes the reference's record stores
-// the same fields here.  The normals are stored as the reference's object loop leaves them; the
-// tail of intersect() (normalisation, vertex-normal interpolation, utils.cpp:807-853) is
-// applied by the shading kernel.  code: -2 no ray (padding item), -1 miss, 1 hit.
-struct HitBuf {
-    double* dist;
-    double* px; double* py; double* pz;
-    double* gx; double* gy; double* gz;     // geometric normal
-    double* sx; double* sy; double* sz;     // shading normal
-    double* beta; double* gamma;
-    int32_t* code;                          // completion status, written last
-    int32_t* mat; int32_t* kind; int32_t* container; int32_t* face; int32_t* tri; int32_t* src;
+// Ray queue: radiance rays occupy slots 0, 1, ... and shadow rays slots capacity-1,
+// capacity-2, ...
+struct Queue { Ray* rays; uint32_t capacity, pad; };
+
+// Closest-hit record of a radiance ray, 128 bytes, indexed by queue slot (by work item for
+// generation 0).  During traversal the record IS the ray's Intersection (scene.h:248-264):
+// every event that writes the reference's record stores the same fields here.  The normals
+// are stored as the reference's object loop leaves them; the tail of intersect()
+// (normalisation, vertex-normal interpolation, utils.cpp:807-853) is applied by the shading
+// kernel.  code: -2 no ray (padding item), -1 miss, 1 hit.
+struct alignas(16) Hit {
+    double dist, p[3], g[3], s[3], beta, gamma;            // g geometric, s shading normal
+    int32_t face, tri, mat, container;
+    int32_t kind, src, code, pad;                          // code: completion status, written last
 };
+static_assert(sizeof(Hit) == 128, "Hit must be 128 bytes");
+struct HitBuf { Hit* recs; };
 
 // Control block of one generation.  counts packs the number of radiance rays (low half) and
 // shadow rays (high half) so that one 64-bit atomic reserves slots at either end of the

@@ -181,6 +181,7 @@ RTX_DEV unsigned lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amd
 // Address-space-qualified views: LDS rows and the private traversal stack are passed to
 // out-of-line code through these so that ds_* and scratch_* instructions are used (a plain
 // pointer would be generic and turn every access into a flat_* instruction).
+#define RTX_GLOBAL __attribute__((address_space(1)))
 typedef __attribute__((address_space(3))) double lds_double;
 typedef double v2d __attribute__((ext_vector_type(2)));
 typedef int v4i __attribute__((ext_vector_type(4)));
@@ -193,14 +194,14 @@ struct Wave { lds_double* rows; unsigned lane; };
 // Wave-cooperative gather of one record per requesting lane into that lane's 128-byte LDS
 // row.  `mask` = ballot of the requesting lanes; `key` (valid in requesting lanes) names the
 // record: key >= 0 is BLAS node `key` (128 bytes), key < 0 is triangle `key & 0x7fffffff`
-// (80 bytes).  In round g lane l serves owner 8g + l/8, so one LDS-DMA instruction
+// (its first tri_pieces 16-byte pieces).  In round g lane l serves owner 8g + l/8, so one LDS-DMA instruction
 // (destination = wave-uniform base + 16*lane) fills the rows of owners 8g..8g+7 with up to 8
 // whole records.  To keep the owners' later 16-byte row reads free of bank conflicts the
 // pieces are stored XOR-swizzled: slot s of owner w holds piece s ^ ((w >> 1) & 7) -- applied
 // to the *source* address here and to the slot index in row_read.  Must be executed by every
 // lane of the wave.
 RTX_DEV void coop_fetch(const Wave& wv, unsigned long long mask, int key, const char* __restrict__ nodes,
-                        const char* __restrict__ tris) {
+                        const char* __restrict__ tris, const unsigned tri_pieces) {
     const unsigned sub = wv.lane >> 3, slot = wv.lane & 7u;
     // all eight cross-lane reads first, so that their latencies overlap
     int okeys[8];
@@ -214,7 +215,7 @@ RTX_DEV void coop_fetch(const Wave& wv, unsigned long long mask, int key, const 
             const int okey = okeys[g];
             const unsigned piece = slot ^ (((unsigned)owner >> 1) & 7u);
             const bool is_tri = okey < 0;
-            if (((gm >> sub) & 1u) && (!is_tri || piece < 5u)) {
+            if (((gm >> sub) & 1u) && (!is_tri || piece < tri_pieces)) {
                 const unsigned idx = (unsigned)okey & 0x7FFFFFFFu;
                 const char* gp = (is_tri ? tris + (size_t)idx * sizeof(Tri) : nodes + (size_t)idx * sizeof(Node)) + piece * 16u;
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gp,
@@ -429,18 +430,19 @@ enum { LS_EMPTY = 0, LS_NEED_JOB = 1, LS_JOB_DONE = 2, LS_IN_JOB = 3 };
 #define RTX_SERVICE_THRESHOLD 24     // lanes waiting for service that trigger a service pass
 #define RTX_CHUNK 256                // rays a wave claims per atomic
 #ifndef RTX_TRACE_WAVES
-#define RTX_TRACE_WAVES 4            // waves per SIMD the trace kernel is compiled for (<= 128 VGPRs)
+#define RTX_TRACE_WAVES 2            // waves per SIMD the trace kernel is compiled for (2: 256 VGPRs)
 #endif
 
 struct Lane {
-    V3 d;                   // world-space direction (the origin is re-read when needed)
+    V3 o, d;                // world-space ray
     double t_min, dist;     // current bound; Intersection::distance of the record
-    unsigned slot;          // queue slot (work item for generation 0) = hit-buffer slot
+    unsigned slot;          // queue slot (work item for generation 0) = hit-record slot
     int is_shadow, hit;
-    // object iterator: it <= n_meshes: meshes (job = mesh it-1); it > n_meshes: instances (job = last)
+    // object iterator: it <= n_meshes: meshes (job = object it-1); it > n_meshes: instances (job = object n_meshes + last)
     int it, last, more;
     int buf[RTX_CAND];
     // current traversal job
+    int obj;
     double orig_t_min;
     V3 ro, rd;
     double ix, iy, iz;
@@ -452,31 +454,27 @@ struct Lane {
 
 // Where a lane's record goes.  Shadow rays need only (hit, distance), which stay in registers.
 struct RecOut {
-    HitBuf hb; unsigned slot; bool on; bool ids;
+    RTX_GLOBAL Hit* rec; bool on; bool ids;
     RTX_DEV void geom(double dist, V3 p, V3 g, V3 s) const {
         if (!on) return;
-        hb.dist[slot] = dist;
-        hb.px[slot] = p.x; hb.py[slot] = p.y; hb.pz[slot] = p.z;
-        hb.gx[slot] = g.x; hb.gy[slot] = g.y; hb.gz[slot] = g.z;
-        hb.sx[slot] = s.x; hb.sy[slot] = s.y; hb.sz[slot] = s.z;
+        rec->dist = dist;
+        rec->p[0] = p.x; rec->p[1] = p.y; rec->p[2] = p.z;
+        rec->g[0] = g.x; rec->g[1] = g.y; rec->g[2] = g.z;
+        rec->s[0] = s.x; rec->s[1] = s.y; rec->s[2] = s.z;
     }
     RTX_DEV void bary(double beta, double gamma, int face, int tri) const {
         if (!on) return;
-        hb.beta[slot] = beta; hb.gamma[slot] = gamma; hb.face[slot] = face; hb.tri[slot] = tri;
+        rec->beta = beta; rec->gamma = gamma; rec->face = face; rec->tri = tri;
     }
-    RTX_DEV void owner(int mat, int container) const { if (on) { hb.mat[slot] = mat; hb.container[slot] = container; } }
-    RTX_DEV void kind(int k) const { if (on) hb.kind[slot] = k; }
-    RTX_DEV void src(int s) const { if (on && ids) hb.src[slot] = s; }
+    RTX_DEV void owner(int mat, int container) const { if (on) { rec->mat = mat; rec->container = container; } }
+    RTX_DEV void kind(int k) const { if (on) rec->kind = k; }
+    RTX_DEV void src(int s) const { if (on && ids) rec->src = s; }
 };
-
-RTX_DEV Slab lane_slab(const Lane& L) {
-    Slab s; s.ox = L.ro.x; s.oy = L.ro.y; s.oz = L.ro.z; s.ix = L.ix; s.iy = L.iy; s.iz = L.iz; s.par = L.par; return s;
-}
 
 // A fresh ray: empty record, then the classes that come before the meshes
 // (planes, utils.cpp:683-685; free triangles, utils.cpp:692-729).
 template <bool COUNT>
-RTX_DEV void ray_begin(const Scene& S, Lane& L, V3 o, const RecOut& out, Tally& tl) {
+RTX_DEV void ray_begin(const Scene& S, Lane& L, const RecOut& out, Tally& tl) {
     L.t_min = DBL_MAX;
     L.dist = 0.0;
     L.hit = 0;
@@ -486,8 +484,8 @@ RTX_DEV void ray_begin(const Scene& S, Lane& L, V3 o, const RecOut& out, Tally& 
         r.point = mk(0, 0, 0); r.gn = mk(0, 0, 0); r.sn = mk(0, 0, 0);
         r.kind = RTX_KIND_NONE; r.container = -1; r.face = -1; r.tri = -1; r.mat = -1; r.src = -1;
         bool hit = false;
-        for (int i = 0; i < S.n_planes; i++) hit = plane_hit(S, o, L.d, i, L.t_min, r) || hit;
-        for (int i = 0; i < S.n_ftris; i++) free_tri_hit<COUNT>(S, o, L.d, i, L.t_min, r, hit, tl);
+        for (int i = 0; i < S.n_planes; i++) hit = plane_hit(S, L.o, L.d, i, L.t_min, r) || hit;
+        for (int i = 0; i < S.n_ftris; i++) free_tri_hit<COUNT>(S, L.o, L.d, i, L.t_min, r, hit, tl);
         if (r.hit) {
             out.geom(r.dist, r.point, r.gn, r.sn);
             out.bary(r.beta, r.gamma, r.face, r.tri);
@@ -504,28 +502,16 @@ RTX_DEV void ray_begin(const Scene& S, Lane& L, V3 o, const RecOut& out, Tally& 
     L.state = LS_NEED_JOB;
 }
 
-// Mesh, transform, material and producing-object id of the lane's current job.
-RTX_DEV void job_ids(const Scene& S, const Lane& L, int& mi, int& xfi, int& mat, int& src) {
-    if (L.it <= S.n_meshes) {
-        mi = L.it - 1;
-        const Mesh& m = S.meshes[mi];
-        xfi = m.xform; mat = m.material; src = mi;
-    } else {
-        const Inst& in = S.insts[L.last];
-        mi = in.base_mesh; xfi = in.xform; mat = in.material; src = S.n_meshes + L.last;
-    }
-}
-
 // Advance the lane's object iterator until an object needs traversal (returns true, job set
 // up: rayHitsMesh's prologue, utils.cpp:418-494 + the root test of bvh.cpp:132) or the
 // object sequence is exhausted (returns false).
 template <bool COUNT>
-RTX_DEV bool job_next(const Scene& S, Lane& L, V3 o, const RecOut& out, Tally& tl) {
+RTX_DEV bool job_next(const Scene& S, Lane& L, const RecOut& out, Tally& tl) {
+    const RTX_GLOBAL Obj* const objs = (const RTX_GLOBAL Obj*)S.objs;
     while (true) {
-        int mi, xfi;
+        int oi;
         if (L.it < S.n_meshes) {                                     // utils.cpp:736-739
-            mi = L.it; L.it++;
-            xfi = S.meshes[mi].xform;
+            oi = L.it; L.it++;
         } else {
             if (L.it == S.n_meshes) {                                // utils.cpp:746-748
                 L.it++;
@@ -534,7 +520,7 @@ RTX_DEV bool job_next(const Scene& S, Lane& L, V3 o, const RecOut& out, Tally& t
                     r.kind = -1; r.dist = 0.0; r.hit = 0; r.mat = -1; r.container = -1; r.src = -1;
                     r.point = mk(0, 0, 0); r.gn = r.point; r.sn = r.point;
                     bool hit = L.hit != 0;
-                    for (int i = 0; i < S.n_spheres; i++) hit = sphere_hit(S, o, L.d, i, L.t_min, r) || hit;
+                    for (int i = 0; i < S.n_spheres; i++) hit = sphere_hit(S, L.o, L.d, i, L.t_min, r) || hit;
                     if (r.kind != -1) {                              // fields a sphere hit writes, utils.cpp:269-291
                         out.geom(r.dist, r.point, r.gn, r.sn);
                         out.owner(r.mat, r.container);
@@ -552,7 +538,7 @@ RTX_DEV bool job_next(const Scene& S, Lane& L, V3 o, const RecOut& out, Tally& t
             // index, RTX_CAND at a time, through the reference's own per-instance logic.
             if (L.buf[0] == INT_MAX) {
                 if (!L.more) return false;
-                const Slab ws = make_slab(o, L.d);
+                const Slab ws = make_slab(L.o, L.d);
                 tlas_collect<COUNT>(S, ws, L.t_min, L.last, L.buf, tl);
                 L.more = L.buf[RTX_CAND - 1] != INT_MAX ? 1 : 0;
                 if (L.buf[0] == INT_MAX) return false;
@@ -562,30 +548,35 @@ RTX_DEV bool job_next(const Scene& S, Lane& L, V3 o, const RecOut& out, Tally& t
             for (int q = 0; q + 1 < RTX_CAND; q++) L.buf[q] = L.buf[q + 1];
             L.buf[RTX_CAND - 1] = INT_MAX;
             L.last = idx;
-            const Inst& in = S.insts[idx];
-            mi = in.base_mesh; xfi = in.xform;
+            oi = S.n_meshes + idx;
         }
-        const Mesh& m = S.meshes[mi];
-        if (m.n_faces <= 0) continue;
-        V3 ro = o, rd = L.d;
-        if (xfi >= 0) {
-            const Xform& xf = S.xforms[xfi];
-            if (xf.has_bounds) {                                     // utils.cpp:446-466, 760-766
+        const RTX_GLOBAL Obj* ob = objs + oi;
+        const int flags = ob->flags;
+        if (flags & OBJ_SKIP) continue;
+        V3 ro = L.o, rd = L.d;
+        if (flags & OBJ_XF) {
+            if (flags & OBJ_BOUNDS) {                                // utils.cpp:446-466, 760-766
                 if (COUNT) tl.world_box++;
-                const Slab ws = make_slab(o, L.d);
+                const Slab ws = make_slab(L.o, L.d);
+                double bmin[3] = {ob->bmin[0], ob->bmin[1], ob->bmin[2]}, bmax[3] = {ob->bmax[0], ob->bmax[1], ob->bmax[2]};
                 double enter;
-                if (!box_enter(xf.bmin, xf.bmax, ws, enter) || !(L.t_min >= enter)) continue;
+                if (!box_enter(bmin, bmax, ws, enter) || !(L.t_min >= enter)) continue;
             }
             if (COUNT) tl.obj_trav++;
-            ro = xf_point(xf.inv, o);                                // utils.cpp:481-489
-            rd = normalize_f32(xf_dir(xf.inv, L.d));
+            double inv[16];
+#pragma unroll
+            for (int k = 0; k < 16; k++) inv[k] = ob->inv[k];
+            ro = xf_point(inv, L.o);                                 // utils.cpp:481-489
+            rd = normalize_f32(xf_dir(inv, L.d));
         }
         const Slab sl = make_slab(ro, rd);
+        double rmin[3] = {ob->rmin[0], ob->rmin[1], ob->rmin[2]}, rmax[3] = {ob->rmax[0], ob->rmax[1], ob->rmax[2]};
         double enter;
-        if (!box_enter(m.rmin, m.rmax, sl, enter) || !(L.t_min >= enter)) continue;
+        if (!box_enter(rmin, rmax, sl, enter) || !(L.t_min >= enter)) continue;
+        L.obj = oi;
         L.orig_t_min = L.t_min;
         L.ro = ro; L.rd = rd; L.ix = sl.ix; L.iy = sl.iy; L.iz = sl.iz; L.par = sl.par;
-        L.cur_ref = m.root_ref; L.cur_cnt = m.root_count; L.sp = 0; L.btri = -1;
+        L.cur_ref = ob->root_ref; L.cur_cnt = ob->root_count; L.sp = 0; L.btri = -1;
         return true;
     }
 }
@@ -594,30 +585,35 @@ RTX_DEV bool job_next(const Scene& S, Lane& L, V3 o, const RecOut& out, Tally& t
 // (utils.cpp:533-668), including the fields the winning triangle test wrote
 // (utils.cpp:370-381, bvh.cpp:162).  beta and gamma of the winning triangle are recomputed
 // here with the same arithmetic that accepted it (same inputs, same bits).
-RTX_DEV void job_finalize(const Scene& S, Lane& L, V3 o, const RecOut& out) {
+RTX_DEV void job_finalize(const Scene& S, Lane& L, const RecOut& out) {
     if (L.btri < 0) return;
-    int mi, xfi, mat, src;
-    job_ids(S, L, mi, xfi, mat, src);
     const int tri = L.btri;
-    const Tri& T = S.tris[tri];
+    const RTX_GLOBAL Tri* Tg = (const RTX_GLOBAL Tri*)S.tris + tri;
+    const RTX_GLOBAL Obj* ob = (const RTX_GLOBAL Obj*)S.objs + L.obj;
+    double T[9];
+#pragma unroll
+    for (int k = 0; k < 3; k++) { T[k] = Tg->a[k]; T[3 + k] = Tg->e1[k]; T[6 + k] = Tg->e2[k]; }
+    const int face = Tg->face;
+    const V3 gn = mk(Tg->gn[0], Tg->gn[1], Tg->gn[2]);
+    const int flags = ob->flags, mat = ob->material, mi = ob->mesh;
     double t, beta, gamma;
-    tri_test(T.a, L.ro, L.rd, INFINITY, S.isect_eps, t, beta, gamma);
-    const V3 a = ld3(T.a), e1 = ld3(T.e1), e2 = ld3(T.e2);
+    tri_test(T, L.ro, L.rd, INFINITY, S.isect_eps, t, beta, gamma);
+    const V3 a = mk(T[0], T[1], T[2]), e1 = mk(T[3], T[4], T[5]), e2 = mk(T[6], T[7], T[8]);
     const V3 point = vadd(vadd(a, sscale(beta, e1)), sscale(gamma, e2));
-    const V3 gn = ld3(S.tri_gn + 3 * (size_t)tri);
-    out.bary(beta, gamma, T.face, tri);
+    out.bary(beta, gamma, face, tri);
     out.kind(RTX_KIND_MESH);
-    if (xfi < 0) {
+    if (!(flags & OBJ_XF)) {
         out.geom(L.t_min, point, gn, gn);
         out.owner(mat, mi);
-        out.src(src);
+        out.src(L.obj);
         L.dist = L.t_min; L.hit = 1;
         return;
     }
-    const Xform& xf = S.xforms[xfi];
-    const Mesh& m = S.meshes[mi];
-    V3 wp = xf_point(xf.m, point);
-    double dx = wp.x - o.x, dy = wp.y - o.y, dz = wp.z - o.z;
+    double m[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) m[k] = ob->m[k];
+    V3 wp = xf_point(m, point);
+    double dx = wp.x - L.o.x, dy = wp.y - L.o.y, dz = wp.z - L.o.z;
     double wd = (double)sqrtf((float)(dx * dx + dy * dy + dz * dz));
     if (wd >= L.orig_t_min) {             // utils.cpp:567-570: bound restored, record is not
         out.geom(L.t_min, point, gn, gn);
@@ -626,20 +622,23 @@ RTX_DEV void job_finalize(const Scene& S, Lane& L, V3 o, const RecOut& out) {
         L.t_min = L.orig_t_min;
         return;
     }
-    V3 wg = normalize_f32(xf_dir(xf.nrm, gn));
+    double nrm[12];
+#pragma unroll
+    for (int k = 0; k < 12; k++) nrm[k] = ob->nrm[k];
+    V3 wg = normalize_f32(xf_dir(nrm, gn));
     V3 ws;
-    if (m.smooth && m.has_vn) {           // utils.cpp:589-621
+    if (flags & OBJ_SMOOTH_VN) {          // utils.cpp:589-621
         double u = beta, v = gamma, w = 1.0 - u - v;
-        const double* vn = S.tri_vn + 9 * (size_t)tri;
+        const RTX_GLOBAL double* vn = (const RTX_GLOBAL double*)S.tri_vn + RTX_VN_STRIDE * (size_t)tri;
         double nx = w * vn[0] + u * vn[3] + v * vn[6];
         double ny = w * vn[1] + u * vn[4] + v * vn[7];
         double nz = w * vn[2] + u * vn[5] + v * vn[8];
         double nlen = (double)sqrtf((float)(nx * nx + ny * ny + nz * nz));
         double ninv = 1.0 / nlen;
         nx *= ninv; ny *= ninv; nz *= ninv;
-        ws = xf_dir(xf.nrm, mk(nx, ny, nz));
+        ws = xf_dir(nrm, mk(nx, ny, nz));
     } else {
-        ws = xf_dir(xf.nrm, gn);
+        ws = xf_dir(nrm, gn);
     }
     {
         double slen = (double)sqrtf((float)(ws.x * ws.x + ws.y * ws.y + ws.z * ws.z));
@@ -649,7 +648,7 @@ RTX_DEV void job_finalize(const Scene& S, Lane& L, V3 o, const RecOut& out) {
     if (dot(wg, L.d) > 0.0) { wg = vneg(wg); ws = vneg(ws); }
     out.geom(wd, wp, wg, ws);
     out.owner(mat, -2);
-    out.src(src);
+    out.src(L.obj);
     L.dist = wd;
     L.t_min = wd;
     L.hit = 1;
@@ -705,10 +704,11 @@ RTX_DEV void emit(const Queue& q, GenCtrl* next, bool shadow, bool want, V3 o, V
     if (want) {
         const unsigned k = base + (unsigned)__popcll(mask & ((1ull << lane) - 1ull));
         const unsigned idx = shadow ? q.capacity - 1u - k : k;
-        q.ox[idx] = o.x; q.oy[idx] = o.y; q.oz[idx] = o.z;
-        q.dx[idx] = d.x; q.dy[idx] = d.y; q.dz[idx] = d.z;
-        q.wx[idx] = w.x; q.wy[idx] = w.y; q.wz[idx] = w.z;
-        q.aux[idx] = aux; q.pixel[idx] = pixel; q.meta[idx] = meta;
+        RTX_GLOBAL Ray* r = (RTX_GLOBAL Ray*)q.rays + idx;
+        r->o[0] = o.x; r->o[1] = o.y; r->o[2] = o.z;
+        r->d[0] = d.x; r->d[1] = d.y; r->d[2] = d.z;
+        r->w[0] = w.x; r->w[1] = w.y; r->w[2] = w.z;
+        r->aux = aux; r->pixel = pixel; r->meta = meta;
     }
 }
 
@@ -748,40 +748,36 @@ RTX_DEV unsigned queue_slot(unsigned w, unsigned n_radiance, unsigned capacity) 
     return w < n_radiance ? w : capacity - 1u - (w - n_radiance);
 }
 
-// Divergent per-lane part of a service pass, kept out of line: the traversal loop then only
-// pays (in registers) for what a traversal step needs, and the hot state is saved around the
-// call.  `fresh`: the lane has just been handed a new ray (L.slot / L.d / L.is_shadow set).
+// Divergent per-lane part of a service pass.  `fresh`: the lane has just been handed a new ray
+// (L.slot / L.o / L.d / L.is_shadow set).
 template <bool COUNT>
-__device__ __noinline__ void service_lane(const Launch* __restrict__ Lp, const int gen, double* __restrict__ accum,
-                                          rtx_hit_id* __restrict__ aov, Lane& L, const bool fresh, Tally& tl) {
+RTX_DEV void service_lane(const Launch* __restrict__ Lp, const int gen, double* __restrict__ accum,
+                          rtx_hit_id* __restrict__ aov, Lane& L, const bool fresh, Tally& tl) {
     const Scene& S = Lp->S;
     const Frame& F = Lp->F;
     const Queue& qin = Lp->q[(gen + 1) & 1];
-    const HitBuf& hb = Lp->hb;
     const unsigned slot = L.slot;
-    const V3 o = gen == 0 ? ld3(F.e) : mk(qin.ox[slot], qin.oy[slot], qin.oz[slot]);
     RecOut out;
-    out.hb = hb; out.slot = slot; out.on = L.is_shadow == 0; out.ids = (gen == 0 && aov != nullptr);
+    out.rec = (RTX_GLOBAL Hit*)Lp->hb.recs + slot; out.on = L.is_shadow == 0; out.ids = (gen == 0 && aov != nullptr);
     long long c0 = COUNT ? clock64() : 0;
     if (fresh) {
         if (COUNT) { tl.rays++; if (gen == 0) tl.primary++; else if (L.is_shadow) tl.shadow++; else tl.secondary++; }
-        ray_begin<COUNT>(S, L, o, out, tl);
+        ray_begin<COUNT>(S, L, out, tl);
         if (COUNT) { const long long c = clock64(); tl.sec[0] += (unsigned long long)(c - c0); tl.sec[4]++; c0 = c; }
     }
     if (L.state == LS_JOB_DONE) {
-        job_finalize(S, L, o, out); L.state = LS_NEED_JOB;
+        job_finalize(S, L, out); L.state = LS_NEED_JOB;
         if (COUNT) { const long long c = clock64(); tl.sec[1] += (unsigned long long)(c - c0); tl.sec[5]++; c0 = c; }
     }
-    const bool more = job_next<COUNT>(S, L, o, out, tl);
+    const bool more = job_next<COUNT>(S, L, out, tl);
     if (COUNT) { const long long c = clock64(); tl.sec[2] += (unsigned long long)(c - c0); tl.sec[6]++; c0 = c; }
     if (more) { L.state = LS_IN_JOB; return; }
     // ---- ray complete ------------------------------------------------------------------------
     const bool hit = L.hit != 0;
     if (L.is_shadow) {                                            // utils.cpp:1083
-        if (!(hit && L.dist < qin.aux[slot]))
-            add_color(accum, qin.pixel[slot], mk(qin.wx[slot], qin.wy[slot], qin.wz[slot]));
+        const RTX_GLOBAL Ray* r = (const RTX_GLOBAL Ray*)qin.rays + slot;
+        if (!(hit && L.dist < r->aux)) add_color(accum, r->pixel, mk(r->w[0], r->w[1], r->w[2]));
     } else {
-        hb.code[slot] = hit ? 1 : -1;
         if (gen == 0 && aov != nullptr) {
             int px, py; unsigned pixel;
             primary_pixel(F, slot, px, py, pixel);
@@ -789,25 +785,26 @@ __device__ __noinline__ void service_lane(const Launch* __restrict__ Lp, const i
             h.kind = 0; h.container = -1; h.face = -1; h.src = -1; h.distance = 0.0;
             if (hit) {
                 // read back what this lane stored (bypassing the vector L1)
-                h.kind = __hip_atomic_load(&hb.kind[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                h.container = __hip_atomic_load(&hb.container[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const int face = __hip_atomic_load(&hb.face[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const int src = __hip_atomic_load(&hb.src[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                Hit* rec = Lp->hb.recs + slot;
+                h.kind = __hip_atomic_load(&rec->kind, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                h.container = __hip_atomic_load(&rec->container, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const int face = __hip_atomic_load(&rec->face, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const int src = __hip_atomic_load(&rec->src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 h.face = (h.kind == RTX_KIND_MESH || h.kind == RTX_KIND_TRIANGLE) ? face : -1;
                 h.src = h.kind == RTX_KIND_MESH ? src : h.container;
                 h.distance = L.dist;
             }
             aov[(size_t)py * F.width + px] = h;
         }
+        out.rec->code = hit ? 1 : -1;
     }
     L.state = LS_EMPTY;
     if (COUNT) { tl.sec[3] += (unsigned long long)(clock64() - c0); tl.sec[7]++; }
 }
 
-// The traversal loop, kept out of line so that its register budget is its own: runs
-// cooperative steps for the lanes that are inside a job until the wave needs a service pass
-// (enough lanes wait for one) or no lane is traversing.  `refillable`: idle lanes could be
-// handed new rays, so they count as waiting for service.
+// The traversal loop: runs cooperative steps for the lanes that are inside a job until the
+// wave needs a service pass (enough lanes wait for one) or no lane is traversing.
+// `refillable`: idle lanes could be handed new rays, so they count as waiting for service.
 //
 // In one step every traversing lane advances by one record: a lane at an inner node gets the
 // node (both child boxes) and descends, a lane in a leaf gets the leaf's next triangle and
@@ -826,129 +823,109 @@ __device__ __noinline__ void service_lane(const Launch* __restrict__ Lp, const i
 // registers (Lane::top); memory holds the entries below it, so the load a pop issues to refill
 // the top is not needed before the next pop and overlaps the next record fetch.
 template <bool COUNT>
-__device__ __noinline__ void traverse_steps(const Launch* __restrict__ Lp, lds_double* rows, Lane& Lmem,
-                                            glob_v4i* __restrict__ stk, const bool refillable, Tally& tlmem) {
-    const Scene& S = Lp->S;
-    Wave wv;
-    wv.lane = lane_id();
-    wv.rows = rows;
+RTX_DEV void traverse_steps(const Scene& S, const Wave& wv, Lane& L, glob_v4i* __restrict__ stk, const bool refillable,
+                            Tally& tl) {
     const unsigned lane = wv.lane;
     const char* const nodes = (const char*)S.nodes;
     const char* const tris = (const char*)S.tris;
-    const double* const tri_gn = S.tri_gn;
     const bool cull = S.cull != 0;
+    const unsigned tri_pieces = cull ? 7u : 5u;
     const double isect_eps = S.isect_eps;
-    // hot state in registers for the duration of the call
-    V3 ro = Lmem.ro, rd = Lmem.rd;
     Slab sl;
-    sl.ox = ro.x; sl.oy = ro.y; sl.oz = ro.z; sl.ix = Lmem.ix; sl.iy = Lmem.iy; sl.iz = Lmem.iz; sl.par = Lmem.par;
-    double t_min = Lmem.t_min;
-    int cur_ref = Lmem.cur_ref, cur_cnt = Lmem.cur_cnt, sp = Lmem.sp, btri = Lmem.btri, state = Lmem.state;
-    v4i top = Lmem.top;
-    unsigned node_visits = 0, tri_tests = 0, inner_steps = 0, inner_lanes = 0, leaf_steps = 0, leaf_lanes = 0;
-    unsigned long long clk_fetch = 0, clk_pop = 0;
+    sl.ox = L.ro.x; sl.oy = L.ro.y; sl.oz = L.ro.z; sl.ix = L.ix; sl.iy = L.iy; sl.iz = L.iz; sl.par = L.par;
 
     while (true) {
-        const bool in_job = state == LS_IN_JOB;
-        const bool at_leaf = in_job && cur_cnt > 0;
+        const bool in_job = L.state == LS_IN_JOB;
+        const bool at_leaf = in_job && L.cur_cnt > 0;
         const unsigned long long m_job = __ballot(in_job);
         if (m_job == 0ull) break;
-        const unsigned long long m_wait = __ballot(state == LS_NEED_JOB || state == LS_JOB_DONE ||
-                                                   (refillable && state == LS_EMPTY));
+        const unsigned long long m_wait = __ballot(L.state == LS_NEED_JOB || L.state == LS_JOB_DONE ||
+                                                   (refillable && L.state == LS_EMPTY));
         if (__popcll(m_wait) >= RTX_SERVICE_THRESHOLD) break;
         if (COUNT && lane == 0) {
             const int nl = __popcll(__ballot(at_leaf)), nj = __popcll(m_job);
-            if (nj > nl) { inner_steps++; inner_lanes += (unsigned)(nj - nl); }
-            if (nl) { leaf_steps++; leaf_lanes += (unsigned)nl; }
+            if (nj > nl) { tl.inner_steps++; tl.inner_lanes += (unsigned)(nj - nl); }
+            if (nl) { tl.leaf_steps++; tl.leaf_lanes += (unsigned)nl; }
         }
 
         const long long f0 = COUNT ? clock64() : 0;
-        coop_fetch(wv, m_job, at_leaf ? (cur_ref | (int)0x80000000) : cur_ref, nodes, tris);
-        if (COUNT) clk_fetch += (unsigned long long)(clock64() - f0);
+        coop_fetch(wv, m_job, at_leaf ? (L.cur_ref | (int)0x80000000) : L.cur_ref, nodes, tris, tri_pieces);
+        if (COUNT) tl.clk_fetch += (unsigned long long)(clock64() - f0);
 
         bool need_pop = false;
         if (in_job) {
             if (!at_leaf) {
-                if (COUNT) node_visits++;
+                if (COUNT) tl.node_visits++;
                 double nd[16];
                 row_read<8>(wv, nd);
                 const int lref = __double2loint(nd[12]), lcnt = __double2hiint(nd[12]);
                 const int rref = __double2loint(nd[13]), rcnt = __double2hiint(nd[13]);
                 const int axis = __double2loint(nd[14]);
                 double el, er;
-                const bool okl = box_enter(nd + 0, nd + 3, sl, el) && (t_min >= el);
-                const bool okr = box_enter(nd + 6, nd + 9, sl, er) && (t_min >= er);
-                const double da = axis == 0 ? rd.x : (axis == 1 ? rd.y : rd.z);
+                const bool okl = box_enter(nd + 0, nd + 3, sl, el) && (L.t_min >= el);
+                const bool okr = box_enter(nd + 6, nd + 9, sl, er) && (L.t_min >= er);
+                const double da = axis == 0 ? L.rd.x : (axis == 1 ? L.rd.y : L.rd.z);
                 const bool left_near = da >= 0.0;
                 const int nref = left_near ? lref : rref, ncnt = left_near ? lcnt : rcnt;
                 const int fref = left_near ? rref : lref, fcnt = left_near ? rcnt : lcnt;
                 const bool okn = left_near ? okl : okr, okf = left_near ? okr : okl;
                 const double ef = left_near ? er : el;
                 if (okn) {
-                    if (okf && sp < RTX_STACK) {
-                        if (sp > 0) stk[sp - 1] = top;
-                        top.x = __double2loint(ef); top.y = __double2hiint(ef); top.z = fref; top.w = fcnt;
-                        sp++;
+                    if (okf && L.sp < RTX_STACK) {
+                        if (L.sp > 0) stk[L.sp - 1] = L.top;
+                        L.top.x = __double2loint(ef); L.top.y = __double2hiint(ef); L.top.z = fref; L.top.w = fcnt;
+                        L.sp++;
                     }
-                    cur_ref = nref; cur_cnt = ncnt;
+                    L.cur_ref = nref; L.cur_cnt = ncnt;
                 } else if (okf) {
-                    cur_ref = fref; cur_cnt = fcnt;
+                    L.cur_ref = fref; L.cur_cnt = fcnt;
                 } else {
                     need_pop = true;
                 }
             } else {
                 // the leaf's next triangle, in leaf order (bvh.cpp:150-170)
-                const int ti = cur_ref;
-                if (COUNT) tri_tests++;
+                const int ti = L.cur_ref;
+                if (COUNT) tl.tri_tests++;
+                double td[14];
                 bool culled = false;
                 if (cull) {
-                    const double* g = tri_gn + 3 * (size_t)ti;
-                    culled = rd.x * g[0] + rd.y * g[1] + rd.z * g[2] > 0.0;
+                    row_read<7>(wv, td);
+                    culled = L.rd.x * td[10] + L.rd.y * td[11] + L.rd.z * td[12] > 0.0;    // utils.cpp:322-326
+                } else {
+                    row_read<5>(wv, td);
                 }
-                double td[10];
-                row_read<5>(wv, td);
                 double t, b, g2;
-                if (!culled && tri_test(td, ro, rd, t_min, isect_eps, t, b, g2)) { t_min = t; btri = ti; }
-                cur_ref++; cur_cnt--;
-                need_pop = cur_cnt == 0;
+                if (!culled && tri_test(td, L.ro, L.rd, L.t_min, isect_eps, t, b, g2)) { L.t_min = t; L.btri = ti; }
+                L.cur_ref++; L.cur_cnt--;
+                need_pop = L.cur_cnt == 0;
             }
         }
         __builtin_amdgcn_wave_barrier();
         const long long p0 = COUNT ? clock64() : 0;
         if (need_pop) {
-            state = LS_JOB_DONE;
-            if (sp > 0) {
+            L.state = LS_JOB_DONE;
+            if (L.sp > 0) {
                 // First pop peeled off the loop: it consumes only registers, and the refill load
                 // it issues stays in flight (inside the loop every iteration has to wait for the
-                // previous iteration's refill).
-                // (everything that reads the old top comes before the load, so the load can
-                // target the registers that hold it)
-                int pass = t_min >= __hiloint2double(top.y, top.x) ? 1 : 0;
-                if (pass) { cur_ref = top.z; cur_cnt = top.w; state = LS_IN_JOB; }
-                asm volatile("" : "+v"(pass), "+v"(cur_ref), "+v"(cur_cnt), "+v"(state));   // old top is dead from here
-                --sp;
-                top = stk[sp > 0 ? sp - 1 : 0];          // (entry 0 is always readable)
+                // previous iteration's refill).  Everything that reads the old top comes before
+                // the load, so the load can target the registers that hold it.
+                int pass = L.t_min >= __hiloint2double(L.top.y, L.top.x) ? 1 : 0;
+                if (pass) { L.cur_ref = L.top.z; L.cur_cnt = L.top.w; L.state = LS_IN_JOB; }
+                asm volatile("" : "+v"(pass), "+v"(L.cur_ref), "+v"(L.cur_cnt), "+v"(L.state));   // old top is dead from here
+                --L.sp;
+                L.top = stk[L.sp > 0 ? L.sp - 1 : 0];          // (entry 0 is always readable)
                 if (!pass) {
-                    while (sp > 0) {
-                        pass = t_min >= __hiloint2double(top.y, top.x);
-                        if (pass) { cur_ref = top.z; cur_cnt = top.w; state = LS_IN_JOB; }
-                        --sp;
-                        if (sp > 0) top = stk[sp - 1];
+                    while (L.sp > 0) {
+                        pass = L.t_min >= __hiloint2double(L.top.y, L.top.x);
+                        if (pass) { L.cur_ref = L.top.z; L.cur_cnt = L.top.w; L.state = LS_IN_JOB; }
+                        --L.sp;
+                        if (L.sp > 0) L.top = stk[L.sp - 1];
                         if (pass) break;
                     }
                 }
             }
         }
-        if (COUNT) clk_pop += (unsigned long long)(clock64() - p0);
-    }
-    Lmem.t_min = t_min;
-    Lmem.cur_ref = cur_ref; Lmem.cur_cnt = cur_cnt; Lmem.sp = sp; Lmem.btri = btri; Lmem.state = state;
-    Lmem.top = top;
-    if (COUNT) {
-        tlmem.node_visits += node_visits; tlmem.tri_tests += tri_tests;
-        tlmem.inner_steps += inner_steps; tlmem.inner_lanes += inner_lanes;
-        tlmem.leaf_steps += leaf_steps; tlmem.leaf_lanes += leaf_lanes;
-        tlmem.clk_fetch += clk_fetch; tlmem.clk_pop += clk_pop;
+        if (COUNT) tl.clk_pop += (unsigned long long)(clock64() - p0);
     }
 }
 
@@ -956,12 +933,14 @@ template <bool COUNT>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RTX_TRACE_WAVES, RTX_TRACE_WAVES)))
 k_trace(const Launch* __restrict__ Lp, GenCtrl* ctrl, const int gen, double* __restrict__ accum,
         rtx_hit_id* __restrict__ aov, Counters* __restrict__ counters) {
+    const Scene& S = Lp->S;
     const Frame& F = Lp->F;
     const Queue& qin = Lp->q[(gen + 1) & 1];
-    const HitBuf& hb = Lp->hb;
     __shared__ __attribute__((aligned(16))) double lds_rows[4][64 * RTX_ROW_DOUBLES];
-    lds_double* rows = (lds_double*)&lds_rows[threadIdx.x >> 6][0];
-    const unsigned lane = lane_id();
+    Wave wv;
+    wv.rows = (lds_double*)&lds_rows[threadIdx.x >> 6][0];
+    wv.lane = lane_id();
+    const unsigned lane = wv.lane;
     GenCtrl* me = ctrl + gen;
     unsigned n_rad = 0, n_in = 0;
     if (gen == 0) { n_rad = (unsigned)F.n_items0; n_in = n_rad; }
@@ -985,13 +964,12 @@ k_trace(const Launch* __restrict__ Lp, GenCtrl* ctrl, const int gen, double* __r
     unsigned chunk_next = 0, chunk_end = 0;      // wave-uniform
     bool drained = false;                        // wave-uniform: the generation has no rays left
 
-    // The lane state and the traversal stack live in private memory; the two out-of-line
-    // phases load what they need.
     glob_v4i* const stk = (glob_v4i*)Lp->stacks +
                           ((size_t)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 64u + lane) * RTX_STACK;
     Lane L;
-    L.state = LS_EMPTY; L.cur_cnt = 0; L.cur_ref = 0; L.sp = 0; L.slot = 0; L.is_shadow = 0; L.btri = -1;
+    L.state = LS_EMPTY; L.cur_cnt = 0; L.cur_ref = 0; L.sp = 0; L.slot = 0; L.is_shadow = 0; L.btri = -1; L.obj = 0;
     L.top = (v4i)(0); L.t_min = 0.0; L.ro = mk(0, 0, 0); L.rd = mk(0, 0, 1); L.ix = L.iy = L.iz = 0.0; L.par = 0;
+    L.o = mk(0, 0, 0); L.d = mk(0, 0, 1);
 
     while (true) {
         const int state = L.state;
@@ -1022,12 +1000,17 @@ k_trace(const Launch* __restrict__ Lp, GenCtrl* ctrl, const int gen, double* __r
                             if (gen == 0) {
                                 int px, py; unsigned pixel;
                                 L.slot = item; L.is_shadow = 0;
-                                if (primary_pixel(F, item, px, py, pixel)) { L.d = primary_direction(F, px, py); fresh = true; }
-                                else hb.code[item] = -2;               // padding item outside the image
+                                if (primary_pixel(F, item, px, py, pixel)) {
+                                    L.o = ld3(F.e); L.d = primary_direction(F, px, py); fresh = true;
+                                } else {
+                                    ((RTX_GLOBAL Hit*)Lp->hb.recs + item)->code = -2;      // padding item outside the image
+                                }
                             } else {
                                 L.is_shadow = item >= n_rad ? 1 : 0;
                                 L.slot = queue_slot(item, n_rad, qin.capacity);
-                                L.d = mk(qin.dx[L.slot], qin.dy[L.slot], qin.dz[L.slot]);
+                                const RTX_GLOBAL Ray* r = (const RTX_GLOBAL Ray*)qin.rays + L.slot;
+                                L.o = mk(r->o[0], r->o[1], r->o[2]);
+                                L.d = mk(r->d[0], r->d[1], r->d[2]);
                                 fresh = true;
                             }
                         }
@@ -1043,7 +1026,7 @@ k_trace(const Launch* __restrict__ Lp, GenCtrl* ctrl, const int gen, double* __r
         }
         if (m_trav == 0ull) break;
         const long long c1 = COUNT ? clock64() : 0;
-        traverse_steps<COUNT>(Lp, rows, L, stk, !drained, tl);
+        traverse_steps<COUNT>(S, wv, L, stk, !drained, tl);
         if (COUNT) tl.clk_trav += (unsigned long long)(clock64() - c1);
     }
 
@@ -1094,10 +1077,11 @@ k_shade(const Launch* __restrict__ Lp, GenCtrl* ctrl, const int gen, double* __r
             active = primary_pixel(F, slot, px, py, pixel) && active;
             if (active) d = primary_direction(F, px, py);
         } else if (active) {
-            d = mk(qin.dx[slot], qin.dy[slot], qin.dz[slot]);
-            W = mk(qin.wx[slot], qin.wy[slot], qin.wz[slot]);
-            pixel = qin.pixel[slot];
-            const unsigned meta = qin.meta[slot];
+            const RTX_GLOBAL Ray* r = (const RTX_GLOBAL Ray*)qin.rays + slot;
+            d = mk(r->d[0], r->d[1], r->d[2]);
+            W = mk(r->w[0], r->w[1], r->w[2]);
+            pixel = r->pixel;
+            const unsigned meta = r->meta;
             depth = meta & 0xFFu; beer = (int)(meta >> 8) - 1;
         }
 
@@ -1105,37 +1089,37 @@ k_shade(const Launch* __restrict__ Lp, GenCtrl* ctrl, const int gen, double* __r
         int mat = -1;
         V3 P = mk(0, 0, 0), gn = mk(0, 0, 1), sn = mk(0, 0, 1);
         if (active) {
-            const int code = hb.code[slot];
+            const RTX_GLOBAL Hit* h = (const RTX_GLOBAL Hit*)hb.recs + slot;
+            const int code = h->code;
             if (code < 0) {
                 if (depth == 0 && code == -1) add_color(accum, pixel, vmul(W, ld3(S.bg)));      // utils.cpp:1055-1058
             } else {
-                mat = hb.mat[slot];
+                mat = h->mat;
                 if (beer >= 0) {                                                     // utils.cpp:975-984
                     const Material& pm = S.materials[beer];
-                    V3 ab = vscale(ld3(pm.sigma), hb.dist[slot]);
+                    V3 ab = vscale(ld3(pm.sigma), h->dist);
                     W = vmul(W, mk(exp(-ab.x), exp(-ab.y), exp(-ab.z)));
                 }
                 if (mat >= 0) {
                     shade = true;
-                    P = mk(hb.px[slot], hb.py[slot], hb.pz[slot]);
+                    P = mk(h->p[0], h->p[1], h->p[2]);
                     // tail of intersect(), utils.cpp:807-853: normalise both normals; for an
                     // untransformed smooth mesh (or a record a rejected transformed hit left
                     // behind) interpolate the vertex normals and face them against the ray
-                    gn = normalize(mk(hb.gx[slot], hb.gy[slot], hb.gz[slot]));
-                    sn = normalize(mk(hb.sx[slot], hb.sy[slot], hb.sz[slot]));
-                    const int cont = hb.container[slot];
-                    int ptri = -1;
-                    if (hb.kind[slot] == RTX_KIND_MESH && cont >= 0 && cont < S.n_meshes) {
-                        const Mesh& cm = S.meshes[cont];
-                        if (cm.smooth && cm.has_vn) ptri = hb.tri[slot];
+                    gn = normalize(mk(h->g[0], h->g[1], h->g[2]));
+                    sn = normalize(mk(h->s[0], h->s[1], h->s[2]));
+                    const int cont = h->container;
+                    int ptri = -1, pflags = 0;
+                    if (h->kind == RTX_KIND_MESH && cont >= 0 && cont < S.n_meshes) {
+                        pflags = S.objs[cont].flags;          // object `cont` is mesh `cont` itself
+                        if (pflags & OBJ_SMOOTH_VN) ptri = h->tri;
                     }
                     if (ptri >= 0) {
-                        const double u = hb.beta[slot], v = hb.gamma[slot], w = 1.0 - u - v;
-                        const Mesh& pm = S.meshes[cont];
-                        const double* vn = S.tri_vn + 9 * (size_t)ptri;
+                        const double u = h->beta, v = h->gamma, w = 1.0 - u - v;
+                        const double* vn = S.tri_vn + RTX_VN_STRIDE * (size_t)ptri;
                         V3 n0 = ld3(vn), n1 = ld3(vn + 3), n2 = ld3(vn + 6);
                         V3 sm = normalize(vadd(vadd(sscale(w, n0), sscale(u, n1)), sscale(v, n2)));
-                        if (pm.xform >= 0) sm = normalize(xf_dir(S.xforms[pm.xform].nrm, sm));
+                        if (pflags & OBJ_XF) sm = normalize(xf_dir(S.objs[cont].nrm, sm));
                         sn = sm;
                         if (dot(gn, d) > 0.0) { gn = vneg(gn); sn = vneg(sn); }
                         else if (dot(sn, gn) < 0.0) sn = vneg(sn);
