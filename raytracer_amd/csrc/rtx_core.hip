@@ -426,7 +426,7 @@ int tile_geometry(const rtx_camera* cam, int tw, int th, int first, int stride, 
 
 Queue make_queue(void* base, uint32_t cap) {
     Queue q;
-    q.rays = (Ray*)base; q.capacity = cap; q.pad = 0;
+    q.rays = (Ray*)base; q.sub_capacity = cap / RTX_NSUB; q.pad = 0;
     return q;
 }
 constexpr size_t kRayBytes = sizeof(Ray);
@@ -657,7 +657,8 @@ int rtx_render(rtx_scene* sc, const rtx_camera* cam, int32_t tw, int32_t th, int
                 float t_trace = 0.f, t_shade = 0.f;
                 (void)hipEventElapsedTime(&t_trace, gev[2 * gen], gev[2 * gen + 1]);
                 (void)hipEventElapsedTime(&t_shade, gev[2 * gen + 1], gev[2 * gen + 2]);
-                const unsigned long long c = gen == 0 ? (unsigned long long)n_items0 : ctrl[gen].counts;
+                unsigned long long c = (unsigned long long)n_items0;
+                if (gen > 0) { c = 0; for (const SubCount& sub : ctrl[gen].sub) c += sub.counts; }
                 fprintf(stderr, "[rtx] gen %d: radiance %u shadow %u trace %.1f us shade(+resolve) %.1f us\n", gen,
                         (unsigned)c, (unsigned)(c >> 32), t_trace * 1e3, t_shade * 1e3);
             }
@@ -667,7 +668,9 @@ int rtx_render(rtx_scene* sc, const rtx_camera* cam, int32_t tw, int32_t th, int
         uint32_t peak = 0;
         for (const GenCtrl& c : ctrl) {
             overflow |= c.overflow != 0;
-            peak = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(peak, (c.counts & 0xFFFFFFFFull) + (c.counts >> 32)), 0x7FFFFFF0ull);
+            // the fullest sub-queue decides: all sub-queues have the same size
+            for (const SubCount& sub : c.sub)
+                peak = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(peak, ((sub.counts & 0xFFFFFFFFull) + (sub.counts >> 32)) * RTX_NSUB), 0x7FFFFFF0ull);
         }
         if (!overflow) {
             if (stats) {

@@ -132,9 +132,9 @@ struct Frame {
 struct alignas(16) Ray { double o[3], d[3], w[3], aux; uint32_t pixel, meta; double pad; };
 static_assert(sizeof(Ray) == 96, "Ray must be 96 bytes");
 
-// Ray queue: radiance rays occupy slots 0, 1, ... and shadow rays slots capacity-1,
-// capacity-2, ...
-struct Queue { Ray* rays; uint32_t capacity, pad; };
+// Ray queue of RTX_NSUB sub-queues of sub_capacity slots each (see GenCtrl): in a sub-queue,
+// radiance rays occupy slots 0, 1, ... and shadow rays slots sub_capacity-1, sub_capacity-2, ...
+struct Queue { Ray* rays; uint32_t sub_capacity, pad; };
 
 // Closest-hit record of a radiance ray, 128 bytes, indexed by queue slot (by work item for
 // generation 0).  During traversal the record IS the ray's Intersection (scene.h:248-264):
@@ -150,13 +150,17 @@ struct alignas(16) Hit {
 static_assert(sizeof(Hit) == 128, "Hit must be 128 bytes");
 struct HitBuf { Hit* recs; };
 
-// Control block of one generation.  counts packs the number of radiance rays (low half) and
-// shadow rays (high half) so that one 64-bit atomic reserves slots at either end of the
-// queue and observes the other end's fill level at the same instant.
-struct GenCtrl {
-    unsigned head_trace, head_shade;
-    unsigned long long counts;
-    unsigned overflow, pad[3];
+// Control block of one generation.  The queue a generation's rays are appended to is split
+// into RTX_NSUB sub-queues of capacity/RTX_NSUB slots, each with its own counter in its own
+// 128-byte line: appending waves pick a sub-queue by wave number, so reservations do not all
+// serialise on one address.  A counter packs the number of radiance rays (low half) and shadow
+// rays (high half) of its sub-queue, so that one 64-bit atomic reserves slots at either end of
+// the sub-queue and observes the other end's fill level at the same instant.
+#define RTX_NSUB 16
+struct alignas(128) SubCount { unsigned long long counts; unsigned long long pad[15]; };
+struct alignas(128) GenCtrl {
+    SubCount sub[RTX_NSUB];
+    unsigned head_trace, head_shade, overflow, pad[29];
 };
 
 // Everything the kernels of one frame read besides the bulk arrays, kept in device memory so

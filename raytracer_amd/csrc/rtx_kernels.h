@@ -137,6 +137,23 @@ RTX_DEV bool box_enter(const double* mn, const double* mx, const Slab& s, double
     return t1 >= t0;
 }
 
+// The same test for a ray with no "parallel" axis (par == 0), written without branches: the
+// per-axis results are selected, not skipped, so a wave executes one straight instruction
+// stream.  Same operations on the same values as box_enter, hence the same bits.
+RTX_DEV bool box_enter_nopar(const double* mn, const double* mx, const Slab& s, double& enter) {
+    const double ax = (mn[0] - s.ox) * s.ix, bx = (mx[0] - s.ox) * s.ix;
+    const double ay = (mn[1] - s.oy) * s.iy, by = (mx[1] - s.oy) * s.iy;
+    const double az = (mn[2] - s.oz) * s.iz, bz = (mx[2] - s.oz) * s.iz;
+    const bool sx = ax > bx, sy = ay > by, sz = az > bz;
+    const double lox = sx ? bx : ax, hix = sx ? ax : bx;
+    const double loy = sy ? by : ay, hiy = sy ? ay : by;
+    const double loz = sz ? bz : az, hiz = sz ? az : bz;
+    const double t0 = smax(smax(smax(0.0, lox), loy), loz);
+    const double t1 = smin(smin(smin((double)INFINITY, hix), hiy), hiz);
+    enter = t0;
+    return t1 >= t0;
+}
+
 // utils.cpp:327-370 on a pre-gathered triangle (a, e1 = b-a, e2 = c-a).  Accept iff
 // t < t_min (strict).  Back-face culling (utils.cpp:322-326) is applied by the caller.
 RTX_DEV bool tri_test(const double* T, V3 o, V3 d, double t_min, double eps, double& t_out,
@@ -203,25 +220,23 @@ struct Wave { lds_double* rows; unsigned lane; };
 RTX_DEV void coop_fetch(const Wave& wv, unsigned long long mask, int key, const char* __restrict__ nodes,
                         const char* __restrict__ tris, const unsigned tri_pieces) {
     const unsigned sub = wv.lane >> 3, slot = wv.lane & 7u;
-    // all eight cross-lane reads first, so that their latencies overlap
+    // Straight-line code: all eight cross-lane reads first (their latencies overlap), then the
+    // eight loads back to back, each executed by the lanes whose owner requested a record.
     int okeys[8];
 #pragma unroll
     for (int g = 0; g < 8; g++) okeys[g] = __shfl(key, 8 * g + (int)sub);
 #pragma unroll
     for (int g = 0; g < 8; g++) {
-        const unsigned gm = (unsigned)(mask >> (8 * g)) & 0xFFu;        // wave-uniform
-        if (gm) {
-            const int owner = 8 * g + (int)sub;
-            const int okey = okeys[g];
-            const unsigned piece = slot ^ (((unsigned)owner >> 1) & 7u);
-            const bool is_tri = okey < 0;
-            if (((gm >> sub) & 1u) && (!is_tri || piece < tri_pieces)) {
-                const unsigned idx = (unsigned)okey & 0x7FFFFFFFu;
-                const char* gp = (is_tri ? tris + (size_t)idx * sizeof(Tri) : nodes + (size_t)idx * sizeof(Node)) + piece * 16u;
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gp,
-                                                 (__attribute__((address_space(3))) void*)(wv.rows + g * 8 * RTX_ROW_DOUBLES),
-                                                 16, 0, 0);
-            }
+        const unsigned owner = 8u * g + sub;
+        const int okey = okeys[g];
+        const unsigned piece = slot ^ ((owner >> 1) & 7u);
+        const bool is_tri = okey < 0;
+        if (((mask >> owner) & 1ull) && (!is_tri || piece < tri_pieces)) {
+            const unsigned idx = (unsigned)okey & 0x7FFFFFFFu;
+            const char* gp = (is_tri ? tris : nodes) + (size_t)idx * 128u + piece * 16u;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gp,
+                                             (__attribute__((address_space(3))) void*)(wv.rows + g * 8 * RTX_ROW_DOUBLES),
+                                             16, 0, 0);
         }
     }
     // vmcnt(0), as a builtin rather than inline assembly so that the compiler's own wait-count
@@ -682,9 +697,9 @@ RTX_DEV double fresnel_dielectric(double cosTheta, double n1, double n2) {
 #define RTX_META(depth, beer) ((unsigned)(depth) | ((unsigned)((beer) + 1) << 8))
 
 // Append one ray per requesting lane: ballot, one reservation per wave, dense stores.
-// Radiance rays go to slot k, shadow rays to slot capacity-1-k.  Must be reached by every
-// lane of the wave.
-RTX_DEV void emit(const Queue& q, GenCtrl* next, bool shadow, bool want, V3 o, V3 d, V3 w, double aux,
+// `sub` = the wave's sub-queue.  Radiance rays go to slot k of the sub-queue, shadow rays to
+// slot sub_capacity-1-k.  Must be reached by every lane of the wave.
+RTX_DEV void emit(const Queue& q, GenCtrl* next, unsigned sub, bool shadow, bool want, V3 o, V3 d, V3 w, double aux,
                   unsigned pixel, unsigned meta) {
     const unsigned long long mask = __ballot(want);
     if (mask == 0ull) return;
@@ -692,18 +707,19 @@ RTX_DEV void emit(const Queue& q, GenCtrl* next, bool shadow, bool want, V3 o, V
     const int leader = __ffsll((long long)mask) - 1;
     const unsigned n = (unsigned)__popcll(mask);
     unsigned long long old = 0;
-    if ((int)lane == leader) old = atomicAdd(&next->counts, shadow ? ((unsigned long long)n << 32) : (unsigned long long)n);
+    if ((int)lane == leader)
+        old = atomicAdd(&next->sub[sub].counts, shadow ? ((unsigned long long)n << 32) : (unsigned long long)n);
     old = __shfl(old, leader);
     const unsigned base = shadow ? (unsigned)(old >> 32) : (unsigned)old;
     const unsigned other = shadow ? (unsigned)old : (unsigned)(old >> 32);
     // Reservations at both ends are totally ordered by the single atomic word, so
-    // base + n + other <= capacity means these slots are not, and will never be, claimed from
-    // the other end.  Otherwise flag the overflow (the frame is redone with larger queues)
+    // base + n + other <= sub_capacity means these slots are not, and will never be, claimed
+    // from the other end.  Otherwise flag the overflow (the frame is redone with larger queues)
     // and drop the rays.
-    if ((unsigned long long)base + n + other > q.capacity) { if ((int)lane == leader) next->overflow = 1u; return; }
+    if ((unsigned long long)base + n + other > q.sub_capacity) { if ((int)lane == leader) next->overflow = 1u; return; }
     if (want) {
         const unsigned k = base + (unsigned)__popcll(mask & ((1ull << lane) - 1ull));
-        const unsigned idx = shadow ? q.capacity - 1u - k : k;
+        const unsigned idx = sub * q.sub_capacity + (shadow ? q.sub_capacity - 1u - k : k);
         RTX_GLOBAL Ray* r = (RTX_GLOBAL Ray*)q.rays + idx;
         r->o[0] = o.x; r->o[1] = o.y; r->o[2] = o.z;
         r->d[0] = d.x; r->d[1] = d.y; r->d[2] = d.z;
@@ -711,6 +727,41 @@ RTX_DEV void emit(const Queue& q, GenCtrl* next, bool shadow, bool want, V3 o, V
         r->aux = aux; r->pixel = pixel; r->meta = meta;
     }
 }
+
+// The rays one generation received, as a list of work items: all radiance rays (sub-queue
+// after sub-queue), then all shadow rays.  The prefix sums are wave-uniform.
+struct GenItems {
+    unsigned rad_end[RTX_NSUB], sh_end[RTX_NSUB];     // cumulative counts through sub-queue q
+    unsigned n_rad, n_in, sub_capacity;
+
+    RTX_DEV void load(const GenCtrl* me, unsigned sub_cap) {
+        sub_capacity = sub_cap;
+        unsigned r_acc = 0, s_acc = 0;
+#pragma unroll
+        for (int q = 0; q < RTX_NSUB; q++) {
+            // after an overflow the counters may exceed what was stored; clamp (the frame is redone)
+            const unsigned long long c = me->sub[q].counts;
+            const unsigned r = min((unsigned)c, sub_cap);
+            const unsigned sdw = min((unsigned)(c >> 32), sub_cap - r);
+            r_acc += r; s_acc += sdw;
+            rad_end[q] = r_acc; sh_end[q] = s_acc;
+        }
+        n_rad = r_acc; n_in = r_acc + s_acc;
+    }
+    // queue slot of work item w < n_in
+    RTX_DEV unsigned slot(unsigned w, bool& is_shadow) const {
+        is_shadow = w >= n_rad;
+        const unsigned v = is_shadow ? w - n_rad : w;
+        unsigned q = 0, prev = 0;
+#pragma unroll
+        for (int k = 0; k + 1 < RTX_NSUB; k++) {
+            const unsigned e = is_shadow ? sh_end[k] : rad_end[k];
+            if (v >= e) { q = (unsigned)k + 1u; prev = e; }
+        }
+        const unsigned k = v - prev;
+        return q * sub_capacity + (is_shadow ? sub_capacity - 1u - k : k);
+    }
+};
 
 RTX_DEV void add_color(double* accum, unsigned pixel, V3 c) {
     if (c.x != 0.0) atomicAdd(accum + 3 * (size_t)pixel, c.x);
@@ -741,11 +792,6 @@ RTX_DEV V3 primary_direction(const Frame& F, int px, int py) {
     V3 e = ld3(F.e), u = ld3(F.u), v = ld3(F.v), q = ld3(F.q);
     V3 s = vsub(vadd(q, vscale(u, s_u)), vscale(v, s_v));
     return normalize(vsub(s, e));
-}
-
-// Queue slot of trace work item w: radiance rays first, then shadow rays (stored from the back).
-RTX_DEV unsigned queue_slot(unsigned w, unsigned n_radiance, unsigned capacity) {
-    return w < n_radiance ? w : capacity - 1u - (w - n_radiance);
 }
 
 // Divergent per-lane part of a service pass.  `fresh`: the lane has just been handed a new ray
@@ -848,6 +894,10 @@ RTX_DEV void traverse_steps(const Scene& S, const Wave& wv, Lane& L, glob_v4i* _
             if (nl) { tl.leaf_steps++; tl.leaf_lanes += (unsigned)nl; }
         }
 
+        // rays with an axis-parallel component are rare: the wave takes the general box test
+        // only when one of its traversing lanes has one
+        const bool any_par = __ballot(in_job && L.par != 0) != 0ull;
+
         const long long f0 = COUNT ? clock64() : 0;
         coop_fetch(wv, m_job, at_leaf ? (L.cur_ref | (int)0x80000000) : L.cur_ref, nodes, tris, tri_pieces);
         if (COUNT) tl.clk_fetch += (unsigned long long)(clock64() - f0);
@@ -862,8 +912,16 @@ RTX_DEV void traverse_steps(const Scene& S, const Wave& wv, Lane& L, glob_v4i* _
                 const int rref = __double2loint(nd[13]), rcnt = __double2hiint(nd[13]);
                 const int axis = __double2loint(nd[14]);
                 double el, er;
-                const bool okl = box_enter(nd + 0, nd + 3, sl, el) && (L.t_min >= el);
-                const bool okr = box_enter(nd + 6, nd + 9, sl, er) && (L.t_min >= er);
+                bool okl, okr;
+                if (any_par) {
+                    okl = box_enter(nd + 0, nd + 3, sl, el) && (L.t_min >= el);
+                    okr = box_enter(nd + 6, nd + 9, sl, er) && (L.t_min >= er);
+                } else {
+                    const bool hl = box_enter_nopar(nd + 0, nd + 3, sl, el);
+                    const bool hr = box_enter_nopar(nd + 6, nd + 9, sl, er);
+                    okl = hl & (L.t_min >= el);
+                    okr = hr & (L.t_min >= er);
+                }
                 const double da = axis == 0 ? L.rd.x : (axis == 1 ? L.rd.y : L.rd.z);
                 const bool left_near = da >= 0.0;
                 const int nref = left_near ? lref : rref, ncnt = left_near ? lcnt : rcnt;
@@ -942,14 +1000,10 @@ k_trace(const Launch* __restrict__ Lp, GenCtrl* ctrl, const int gen, double* __r
     wv.lane = lane_id();
     const unsigned lane = wv.lane;
     GenCtrl* me = ctrl + gen;
-    unsigned n_rad = 0, n_in = 0;
-    if (gen == 0) { n_rad = (unsigned)F.n_items0; n_in = n_rad; }
-    else {
-        // after an overflow the counters may exceed what was stored; clamp (the frame is redone)
-        const unsigned long long c = me->counts;
-        n_rad = min((unsigned)c, qin.capacity);
-        n_in = n_rad + min((unsigned)(c >> 32), qin.capacity - n_rad);
-    }
+    GenItems items;
+    unsigned n_in;
+    if (gen == 0) n_in = (unsigned)F.n_items0;
+    else { items.load(me, qin.sub_capacity); n_in = items.n_in; }
     Tally tl = {};
     const long long clk_begin = COUNT ? clock64() : 0;
 
@@ -1006,8 +1060,9 @@ k_trace(const Launch* __restrict__ Lp, GenCtrl* ctrl, const int gen, double* __r
                                     ((RTX_GLOBAL Hit*)Lp->hb.recs + item)->code = -2;      // padding item outside the image
                                 }
                             } else {
-                                L.is_shadow = item >= n_rad ? 1 : 0;
-                                L.slot = queue_slot(item, n_rad, qin.capacity);
+                                bool sh;
+                                L.slot = items.slot(item, sh);
+                                L.is_shadow = sh ? 1 : 0;
                                 const RTX_GLOBAL Ray* r = (const RTX_GLOBAL Ray*)qin.rays + L.slot;
                                 L.o = mk(r->o[0], r->o[1], r->o[2]);
                                 L.d = mk(r->d[0], r->d[1], r->d[2]);
@@ -1059,15 +1114,20 @@ k_shade(const Launch* __restrict__ Lp, GenCtrl* ctrl, const int gen, double* __r
     const unsigned lane = lane_id();
     GenCtrl* me = ctrl + gen;
     GenCtrl* next = ctrl + gen + 1;
-    const unsigned n_in = gen == 0 ? (unsigned)F.n_items0 : min((unsigned)me->counts, qin.capacity);
+    GenItems items;
+    unsigned n_in;
+    if (gen == 0) n_in = (unsigned)F.n_items0;
+    else { items.load(me, qin.sub_capacity); n_in = items.n_rad; }
+    const unsigned my_sub = (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) & (RTX_NSUB - 1u);
 
-    while (true) {
-        unsigned base = 0;
-        if (lane == 0) base = atomicAdd(&me->head_shade, 64u);
-        base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
-        if (base >= n_in) break;
-        const unsigned slot = base + lane;
-        bool active = slot < n_in;
+    // Batches of 64 hits are dealt to the waves round-robin: shading cost is nearly uniform, so
+    // a static deal balances as well as a shared counter without serialising on it.
+    const unsigned n_waves = gridDim.x * (blockDim.x >> 6);
+    for (unsigned base = (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 64u; base < n_in; base += n_waves * 64u) {
+        const unsigned item = base + lane;
+        bool active = item < n_in;
+        unsigned slot = item;
+        if (gen != 0 && active) { bool sh; slot = items.slot(item, sh); }
 
         V3 d = mk(0, 0, 1), W = mk(1, 1, 1);
         unsigned pixel = 0, depth = 0;
@@ -1230,10 +1290,10 @@ k_shade(const Launch* __restrict__ Lp, GenCtrl* ctrl, const int gen, double* __r
                 sw = vmul(W, contrib);
                 dist_to_light = sqrt(dot(vsub(lp, P), vsub(lp, P)));
             }
-            emit(qout, next, true, lit, so, sd, sw, dist_to_light, pixel, 0u);
+            emit(qout, next, my_sub, true, lit, so, sd, sw, dist_to_light, pixel, 0u);
         }
-        emit(qout, next, false, c0, c0o, c0d, c0w, 0.0, pixel, RTX_META(depth + 1, -1));
-        emit(qout, next, false, c1, c1o, c1d, c1w, 0.0, pixel, RTX_META(depth + 1, c1beer));
+        emit(qout, next, my_sub, false, c0, c0o, c0d, c0w, 0.0, pixel, RTX_META(depth + 1, -1));
+        emit(qout, next, my_sub, false, c1, c1o, c1d, c1w, 0.0, pixel, RTX_META(depth + 1, c1beer));
     }
 }
 
