@@ -84,7 +84,7 @@ namespace {
 
 // ---- BLAS flattening ---------------------------------------------------------------------
 struct Flat {
-    std::vector<Node> nodes;
+    std::vector<Node4> nodes;
     std::vector<Tri> tris;
     std::vector<double> tri_vn;         // RTX_VN_STRIDE doubles per triangle
     std::vector<Mesh> meshes;
@@ -144,9 +144,8 @@ int flatten_mesh(const rtx_scene_desc& d, const rtx_mesh& m, Flat& F) {
     }
     if (!m.face_indices) return fail(RTX_EINVAL, "mesh BVH without face_indices");
     const int n = m.n_nodes;
-    // device ids for inner nodes, triangle ranges for leaves (in node order = DFS pre-order)
-    std::vector<int32_t> inner_id((size_t)n, -1), leaf_start((size_t)n, -1);
-    int32_t next_inner = (int32_t)F.nodes.size();
+    // triangle ranges for leaves, in node order (= DFS pre-order = the order of faceIndices)
+    std::vector<int32_t> leaf_start((size_t)n, -1);
     for (int i = 0; i < n; i++) {
         const rtx_bvh_node& nd = m.nodes[i];
         if (nd.left == -1) {
@@ -160,26 +159,9 @@ int flatten_mesh(const rtx_scene_desc& d, const rtx_mesh& m, Flat& F) {
         } else {
             if (nd.left < 0 || nd.left >= n || nd.right < 0 || nd.right >= n || nd.split_axis < 0 || nd.split_axis > 2)
                 return fail(RTX_EINVAL, "BVH inner node with invalid children");
-            inner_id[(size_t)i] = next_inner++;
         }
     }
-    F.nodes.resize((size_t)next_inner);
-    auto child = [&](int c, int32_t& ref, int32_t& cnt) {
-        if (m.nodes[c].left == -1) { ref = leaf_start[(size_t)c]; cnt = m.nodes[c].face_count; }
-        else { ref = inner_id[(size_t)c]; cnt = 0; }
-    };
-    for (int i = 0; i < n; i++) {
-        if (inner_id[(size_t)i] < 0) continue;
-        const rtx_bvh_node& nd = m.nodes[i];
-        Node& o = F.nodes[(size_t)inner_id[(size_t)i]];
-        memset(&o, 0, sizeof o);
-        memcpy(o.lmin, m.nodes[nd.left].bounds_min, 24); memcpy(o.lmax, m.nodes[nd.left].bounds_max, 24);
-        memcpy(o.rmin, m.nodes[nd.right].bounds_min, 24); memcpy(o.rmax, m.nodes[nd.right].bounds_max, 24);
-        child(nd.left, o.lref, o.lcount);
-        child(nd.right, o.rref, o.rcount);
-        o.axis = nd.split_axis;
-    }
-    // depth check: the traversal stack holds one entry per level
+    // tree and depth check: a collapsed node pushes up to three entries per two binary levels
     {
         std::vector<std::pair<int, int>> st;
         st.emplace_back(0, 1);
@@ -191,10 +173,42 @@ int flatten_mesh(const rtx_scene_desc& d, const rtx_mesh& m, Flat& F) {
             max_depth = std::max(max_depth, dep);
             if (m.nodes[i].left != -1) { st.emplace_back(m.nodes[i].left, dep + 1); st.emplace_back(m.nodes[i].right, dep + 1); }
         }
-        if (max_depth > RTX_STACK - 2) return fail(RTX_ELIMIT, "BVH deeper than the traversal stack");
+        if (3 * ((max_depth + 1) / 2) > RTX_STACK - 2) return fail(RTX_ELIMIT, "BVH deeper than the traversal stack");
     }
+    // collapse two binary levels per record, records in DFS pre-order
+    struct Collapse {
+        const rtx_mesh& m; const std::vector<int32_t>& leaf_start; Flat& F;
+        void slot(Node4& o, int s, int c, int32_t ref, int32_t cnt) {
+            memcpy(o.box[s], m.nodes[c].bounds_min, 24); memcpy(o.box[s] + 3, m.nodes[c].bounds_max, 24);
+            o.ref[s] = ref; o.cnt[s] = cnt;
+        }
+        int32_t make(int i) {
+            const int32_t id = (int32_t)F.nodes.size();
+            F.nodes.emplace_back();
+            Node4 o;
+            memset(&o, 0, sizeof o);
+            for (int s = 0; s < 4; s++) o.cnt[s] = -1;
+            const rtx_bvh_node& nd = m.nodes[i];
+            o.axis0 = nd.split_axis;
+            const int part[2] = {nd.left, nd.right};
+            for (int p = 0; p < 2; p++) {
+                const rtx_bvh_node& pn = m.nodes[part[p]];
+                if (pn.left == -1) { slot(o, 2 * p, part[p], leaf_start[(size_t)part[p]], pn.face_count); continue; }
+                (p == 0 ? o.axisL : o.axisR) = pn.split_axis;
+                const int kid[2] = {pn.left, pn.right};
+                for (int j = 0; j < 2; j++) {
+                    const rtx_bvh_node& x = m.nodes[kid[j]];
+                    if (x.left == -1) slot(o, 2 * p + j, kid[j], leaf_start[(size_t)kid[j]], x.face_count);
+                    else slot(o, 2 * p + j, kid[j], make(kid[j]), 0);
+                }
+            }
+            F.nodes[(size_t)id] = o;
+            return id;
+        }
+    };
     memcpy(out.rmin, m.nodes[0].bounds_min, 24); memcpy(out.rmax, m.nodes[0].bounds_max, 24);
-    child(0, out.root_ref, out.root_count);
+    if (m.nodes[0].left == -1) { out.root_ref = leaf_start[0]; out.root_count = m.nodes[0].face_count; }
+    else { Collapse c{m, leaf_start, F}; out.root_ref = c.make(0); out.root_count = 0; }
     F.meshes.push_back(out);
     return RTX_OK;
 }
@@ -331,6 +345,7 @@ int build_scene(rtx_scene& sc, const rtx_scene_desc& d) {
         if ((rc = flatten_mesh(d, m, F))) return rc;
     }
     if (F.tris.size() > (size_t)INT_MAX / 2) return fail(RTX_ELIMIT, "too many triangles");
+    { Tri pad_tri; memset(&pad_tri, 0, sizeof pad_tri); F.tris.push_back(pad_tri); }   // leaf steps fetch triangles in pairs
 
     // instances: effective transform (utils.cpp:418,446,476) and TLAS over their world boxes
     std::vector<Inst> insts((size_t)d.n_instances);
@@ -400,7 +415,7 @@ int build_scene(rtx_scene& sc, const rtx_scene_desc& d) {
     HIP_TRY(sc.ftris.upload(ftris));      S.ftris = (const FreeTri*)sc.ftris.p;
     HIP_TRY(sc.meshes.upload(F.meshes));  S.meshes = (const Mesh*)sc.meshes.p;
     HIP_TRY(sc.insts.upload(insts));      S.insts = (const Inst*)sc.insts.p;
-    HIP_TRY(sc.nodes.upload(F.nodes));    S.nodes = (const Node*)sc.nodes.p;
+    HIP_TRY(sc.nodes.upload(F.nodes));    S.nodes = (const Node4*)sc.nodes.p;
     HIP_TRY(sc.tris.upload(F.tris));      S.tris = (const Tri*)sc.tris.p;
     if (F.any_vn) { HIP_TRY(sc.tri_vn.upload(F.tri_vn)); S.tri_vn = (const double*)sc.tri_vn.p; }
     else {

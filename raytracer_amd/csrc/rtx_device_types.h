@@ -2,10 +2,10 @@
 // from an rtx_scene_desc; the kernels read nothing else.
 //
 // Two-level layout:
-//   BLAS  -- per mesh, the reference's own binary BVH (bvh.cpp:187-258) re-packed so that
-//            one 128-byte record holds BOTH children's boxes of an inner node; leaves are
-//            ranges of a triangle array stored in leaf order (the order of
-//            MeshBVH::faceIndices), each triangle pre-gathered as (a, b-a, c-a).
+//   BLAS  -- per mesh, the reference's own binary BVH (bvh.cpp:187-258) re-packed two levels
+//            at a time: one 256-byte record holds the boxes of up to four grandchildren of a
+//            binary node; leaves are ranges of a triangle array stored in leaf order (the
+//            order of MeshBVH::faceIndices), each triangle pre-gathered as (a, b-a, c-a).
 //   TLAS  -- a spatial BVH over the world boxes of the mesh instances, built here (the
 //            reference scans instances linearly, utils.cpp:756-790).  It only *selects
 //            candidates*; candidates are then processed in ascending instance index with
@@ -16,15 +16,22 @@
 
 namespace rtxdev {
 
-// Inner BLAS node.  A child with count == 0 is another inner node (ref = node index);
-// count > 0 is a leaf owning triangles [ref, ref + count) of the global triangle array.
-struct Node {
-    double lmin[3], lmax[3], rmin[3], rmax[3];
-    int32_t lref, lcount, rref, rcount;
-    int32_t axis;          // BVHNode::splitAxis: near child = left iff dir[axis] >= 0
-    int32_t pad[3];
+// Inner BLAS node: two levels of the reference's binary BVH collapsed into one 256-byte
+// record (sixteen 16-byte pieces), so that a traversal step descends two binary levels.
+// Slots 0,1 belong to the left child of the binary node the record stands for, slots 2,3 to its
+// right child: an inner child contributes its own two children, a leaf child sits in the first
+// slot of its pair and leaves the second empty.  cnt: 0 = inner (ref = Node4 index),
+// > 0 = leaf owning triangles [ref, ref + cnt) of the triangle array, -1 = empty slot.
+// axis0 / axisL / axisR are BVHNode::splitAxis of the binary node, its left and its right child:
+// the near side of a split is the left one iff dir[axis] >= 0 (bvh.cpp:139-147).
+struct alignas(16) Node4 {
+    double box[4][6];              // per slot: min xyz, max xyz
+    int32_t ref[4];
+    int32_t cnt[4];
+    int32_t axis0, axisL, axisR, pad0;
+    int32_t pad1[4];
 };
-static_assert(sizeof(Node) == 128, "Node must be 128 bytes");
+static_assert(sizeof(Node4) == 256, "Node4 must be 256 bytes");
 
 // Triangle record, 128 bytes = eight 16-byte pieces.  Pieces 0-4 are what a traversal step
 // needs (vertex a, the edges b - a and c - a, the original face index); pieces 5-6 hold the
@@ -108,7 +115,7 @@ struct Scene {
     const Mesh* meshes;
     const Inst* insts;
     const Obj* objs;          // n_meshes + n_insts records
-    const Node* nodes;
+    const Node4* nodes;
     const Tri* tris;
     const double* tri_vn;     // RTX_VN_STRIDE per triangle (vertex normals of its corners) or null
     const TlasNode* tlas;

@@ -190,8 +190,9 @@ struct Tally { unsigned node_visits, tri_tests, world_box, obj_trav, tlas_visits
                unsigned long long clk_trav, clk_serv, clk_total, clk_fetch, clk_pop;
                unsigned long long sec[8]; };   // per-lane section profile of service_lane: ticks (0-3), calls (4-7)              // shader-clock ticks (lane 0)
 
-#define RTX_STACK 64
-#define RTX_ROW_DOUBLES 16          // one 128-byte LDS row per lane
+#define RTX_STACK 100                // BLAS traversal stack entries per lane (BVH depth <= 64)
+#define RTX_TLAS_STACK 48
+#define RTX_ROW_DOUBLES 32          // one 256-byte LDS row per lane
 
 RTX_DEV unsigned lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 
@@ -208,34 +209,46 @@ typedef __attribute__((address_space(1))) v4i glob_v4i;
 // Per-wave context: this wave's 64 LDS rows and the lane number.
 struct Wave { lds_double* rows; unsigned lane; };
 
-// Wave-cooperative gather of one record per requesting lane into that lane's 128-byte LDS
-// row.  `mask` = ballot of the requesting lanes; `key` (valid in requesting lanes) names the
-// record: key >= 0 is BLAS node `key` (128 bytes), key < 0 is triangle `key & 0x7fffffff`
-// (its first tri_pieces 16-byte pieces).  In round g lane l serves owner 8g + l/8, so one LDS-DMA instruction
-// (destination = wave-uniform base + 16*lane) fills the rows of owners 8g..8g+7 with up to 8
-// whole records.  To keep the owners' later 16-byte row reads free of bank conflicts the
-// pieces are stored XOR-swizzled: slot s of owner w holds piece s ^ ((w >> 1) & 7) -- applied
-// to the *source* address here and to the slot index in row_read.  Must be executed by every
-// lane of the wave.
-RTX_DEV void coop_fetch(const Wave& wv, unsigned long long mask, int key, const char* __restrict__ nodes,
-                        const char* __restrict__ tris, const unsigned tri_pieces) {
-    const unsigned sub = wv.lane >> 3, slot = wv.lane & 7u;
-    // Straight-line code: all eight cross-lane reads first (their latencies overlap), then the
-    // eight loads back to back, each executed by the lanes whose owner requested a record.
-    int okeys[8];
+// Wave-cooperative gather of one 256-byte record per requesting lane into that lane's LDS row.
+// `key` names the record: -1 = no request, otherwise bit 31 clear = BLAS node `key`, bit 31
+// set = the pair of triangle records starting at triangle `key & 0x7fffffff`.
+//
+// Sixteen lanes read one record as sixteen adjacent 16-byte pieces, so one load instruction
+// touches 4 records x 256 contiguous bytes instead of 64 scattered pieces.  The loads are
+// LDS-DMA (global_load_lds_dwordx4, destination = wave-uniform base + 16*lane): in round g
+// lane l serves owner 4g + l/16, and the round fills the rows of owners 4g..4g+3.  The lanes
+// learn their owners' keys through the (still unused) row memory: owner w stores its key at
+// dword (w & 3)*16 + (w >> 2), so the sixteen keys a lane needs are 64 contiguous bytes.
+// To keep the owners' later 16-byte row reads free of bank conflicts the pieces are stored
+// XOR-swizzled: slot s of owner w holds piece s ^ (w & 15) -- applied to the *source* address
+// here and to the slot index in row_read.  Must be executed by every lane of the wave.
+typedef __attribute__((address_space(3))) int lds_int;
+typedef __attribute__((address_space(3))) v4i lds_v4i;
+RTX_DEV void coop_fetch(const Wave& wv, int key, const char* __restrict__ nodes, const char* __restrict__ tris) {
+    const unsigned lane = wv.lane, quarter = lane >> 4, slot = lane & 15u;
+    ((lds_int*)wv.rows)[(lane & 3u) * 16u + (lane >> 2)] = key;
+    __builtin_amdgcn_wave_barrier();
+    int okeys[16];
+    {
+        const lds_v4i* kp = (const lds_v4i*)wv.rows + quarter * 4u;
 #pragma unroll
-    for (int g = 0; g < 8; g++) okeys[g] = __shfl(key, 8 * g + (int)sub);
+        for (int q = 0; q < 4; q++) {
+            const v4i v = kp[q];
+            okeys[4 * q] = v.x; okeys[4 * q + 1] = v.y; okeys[4 * q + 2] = v.z; okeys[4 * q + 3] = v.w;
+        }
+    }
+    // the keys must have left the row memory before the first record lands in it
+    __builtin_amdgcn_s_waitcnt(0xC07F);          // lgkmcnt(0); vmcnt and expcnt left at "no wait"
+    __builtin_amdgcn_wave_barrier();
 #pragma unroll
-    for (int g = 0; g < 8; g++) {
-        const unsigned owner = 8u * g + sub;
+    for (int g = 0; g < 16; g++) {
         const int okey = okeys[g];
-        const unsigned piece = slot ^ ((owner >> 1) & 7u);
-        const bool is_tri = okey < 0;
-        if (((mask >> owner) & 1ull) && (!is_tri || piece < tri_pieces)) {
+        const unsigned piece = slot ^ ((4u * g + quarter) & 15u);
+        if (okey != -1) {
             const unsigned idx = (unsigned)okey & 0x7FFFFFFFu;
-            const char* gp = (is_tri ? tris : nodes) + (size_t)idx * 128u + piece * 16u;
+            const char* gp = (okey < 0 ? tris + (size_t)idx * sizeof(Tri) : nodes + (size_t)idx * sizeof(Node4)) + piece * 16u;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gp,
-                                             (__attribute__((address_space(3))) void*)(wv.rows + g * 8 * RTX_ROW_DOUBLES),
+                                             (__attribute__((address_space(3))) void*)(wv.rows + g * 4 * RTX_ROW_DOUBLES),
                                              16, 0, 0);
         }
     }
@@ -246,14 +259,14 @@ RTX_DEV void coop_fetch(const Wave& wv, unsigned long long mask, int key, const 
     __builtin_amdgcn_wave_barrier();
 }
 
-// Read the first NCHUNK 16-byte pieces of this lane's row (undoing the swizzle) into out[].
-template <int NCHUNK>
+// Read pieces FIRST .. FIRST+N-1 of this lane's row (undoing the swizzle) into out[0 .. 2N).
+template <int FIRST, int N>
 RTX_DEV void row_read(const Wave& wv, double* out) {
     const lds_v2d* r2 = (const lds_v2d*)(wv.rows + wv.lane * RTX_ROW_DOUBLES);
-    const unsigned sw = (wv.lane >> 1) & 7u;
+    const unsigned sw = wv.lane & 15u;
 #pragma unroll
-    for (int p = 0; p < NCHUNK; p++) {
-        const v2d v = r2[(unsigned)p ^ sw];
+    for (int p = 0; p < N; p++) {
+        const v2d v = r2[(unsigned)(FIRST + p) ^ sw];
         out[2 * p] = v.x; out[2 * p + 1] = v.y;
     }
 }
@@ -387,7 +400,7 @@ template <bool COUNT>
 RTX_DEV void tlas_collect(const Scene& S, const Slab& sl, double t_min, int last, int (&buf)[RTX_CAND], Tally& tl) {
     double enter;
     if (!(S.tl_max_idx > last && box_enter(S.tl_min, S.tl_max, sl, enter) && (t_min >= enter))) return;
-    int stk_ref[RTX_STACK], stk_cnt[RTX_STACK];
+    int stk_ref[RTX_TLAS_STACK], stk_cnt[RTX_TLAS_STACK];
     int sp = 1;
     stk_ref[0] = S.tl_ref; stk_cnt[0] = S.tl_count;
     while (sp > 0) {
@@ -410,11 +423,11 @@ RTX_DEV void tlas_collect(const Scene& S, const Slab& sl, double t_min, int last
             if (COUNT) tl.tlas_visits++;
             double e;
             if (n.lmax_idx > last && n.lmin_idx < buf[RTX_CAND - 1] && box_enter(n.lmin, n.lmax, sl, e) &&
-                (t_min >= e) && sp < RTX_STACK) {
+                (t_min >= e) && sp < RTX_TLAS_STACK) {
                 stk_ref[sp] = n.lref; stk_cnt[sp] = n.lcount; sp++;
             }
             if (n.rmax_idx > last && n.rmin_idx < buf[RTX_CAND - 1] && box_enter(n.rmin, n.rmax, sl, e) &&
-                (t_min >= e) && sp < RTX_STACK) {
+                (t_min >= e) && sp < RTX_TLAS_STACK) {
                 stk_ref[sp] = n.rref; stk_cnt[sp] = n.rcount; sp++;
             }
         }
@@ -852,22 +865,33 @@ RTX_DEV void service_lane(const Launch* __restrict__ Lp, const int gen, double* 
 // wave needs a service pass (enough lanes wait for one) or no lane is traversing.
 // `refillable`: idle lanes could be handed new rays, so they count as waiting for service.
 //
-// In one step every traversing lane advances by one record: a lane at an inner node gets the
-// node (both child boxes) and descends, a lane in a leaf gets the leaf's next triangle and
-// tests it.  Both kinds of record arrive through the same cooperative fetch, so the step has
+// In one step every traversing lane advances by one 256-byte record: a lane at an inner node
+// gets the collapsed node (the boxes of up to four grandchildren) and descends two binary
+// levels, a lane in a leaf gets the leaf's next two triangles and tests them in order.  Both kinds of record arrive through the same cooperative fetch, so the step has
 // a single exposed memory latency whatever the mix of lanes.
 //
 // Visit order and visited set of bvh.cpp:104-185: children ordered near/far by the sign of
 // dir[splitAxis] (near first); a node is entered iff its box test passes with the bound current
-// when the reference would pop it.  Both children's boxes are evaluated at their parent; the
-// far child is pushed with its entry distance and re-checked against the (possibly smaller)
-// bound when popped -- the predicate the reference evaluates at that moment.
+// when the reference would pop it.  A child's box is evaluated at its (grand)parent; children
+// that are not entered at once are pushed with their entry distance and re-checked against the
+// (possibly smaller) bound when popped -- the predicate the reference evaluates at that
+// moment.  Skipping the intermediate binary node's own test changes nothing: the slab
+// arithmetic is monotone, so a box that passes lies inside a parent box that passes too, and
+// the bound only shrinks between the parent's turn and the child's.
 //
 // Stack entries are 16 bytes (entry distance, ref, count) in a per-lane region of global
 // memory (private "scratch" arrays interleave lanes dword by dword, which makes a 16-byte
 // access at lane-varying depth touch four cache lines per lane).  The top entry is kept in
 // registers (Lane::top); memory holds the entries below it, so the load a pop issues to refill
 // the top is not needed before the next pop and overlaps the next record fetch.
+// One candidate child of a collapsed node while the visit order is being established.
+struct Cand { double e; int ref, cnt; bool ok; };
+RTX_DEV void cand_swap(Cand& a, Cand& b, bool doit) {
+    const Cand x = a, y = b;
+    a.e = doit ? y.e : x.e; a.ref = doit ? y.ref : x.ref; a.cnt = doit ? y.cnt : x.cnt; a.ok = doit ? y.ok : x.ok;
+    b.e = doit ? x.e : y.e; b.ref = doit ? x.ref : y.ref; b.cnt = doit ? x.cnt : y.cnt; b.ok = doit ? x.ok : y.ok;
+}
+
 template <bool COUNT>
 RTX_DEV void traverse_steps(const Scene& S, const Wave& wv, Lane& L, glob_v4i* __restrict__ stk, const bool refillable,
                             Tally& tl) {
@@ -875,7 +899,6 @@ RTX_DEV void traverse_steps(const Scene& S, const Wave& wv, Lane& L, glob_v4i* _
     const char* const nodes = (const char*)S.nodes;
     const char* const tris = (const char*)S.tris;
     const bool cull = S.cull != 0;
-    const unsigned tri_pieces = cull ? 7u : 5u;
     const double isect_eps = S.isect_eps;
     Slab sl;
     sl.ox = L.ro.x; sl.oy = L.ro.y; sl.oz = L.ro.z; sl.ix = L.ix; sl.iy = L.iy; sl.iz = L.iz; sl.par = L.par;
@@ -893,69 +916,87 @@ RTX_DEV void traverse_steps(const Scene& S, const Wave& wv, Lane& L, glob_v4i* _
             if (nj > nl) { tl.inner_steps++; tl.inner_lanes += (unsigned)(nj - nl); }
             if (nl) { tl.leaf_steps++; tl.leaf_lanes += (unsigned)nl; }
         }
-
         // rays with an axis-parallel component are rare: the wave takes the general box test
         // only when one of its traversing lanes has one
         const bool any_par = __ballot(in_job && L.par != 0) != 0ull;
 
         const long long f0 = COUNT ? clock64() : 0;
-        coop_fetch(wv, m_job, at_leaf ? (L.cur_ref | (int)0x80000000) : L.cur_ref, nodes, tris, tri_pieces);
+        coop_fetch(wv, in_job ? (at_leaf ? (L.cur_ref | (int)0x80000000) : L.cur_ref) : -1, nodes, tris);
         if (COUNT) tl.clk_fetch += (unsigned long long)(clock64() - f0);
 
         bool need_pop = false;
         if (in_job) {
             if (!at_leaf) {
+                // ---- collapsed inner node: up to four grandchildren of a binary node ------------
                 if (COUNT) tl.node_visits++;
-                double nd[16];
-                row_read<8>(wv, nd);
-                const int lref = __double2loint(nd[12]), lcnt = __double2hiint(nd[12]);
-                const int rref = __double2loint(nd[13]), rcnt = __double2hiint(nd[13]);
-                const int axis = __double2loint(nd[14]);
-                double el, er;
-                bool okl, okr;
-                if (any_par) {
-                    okl = box_enter(nd + 0, nd + 3, sl, el) && (L.t_min >= el);
-                    okr = box_enter(nd + 6, nd + 9, sl, er) && (L.t_min >= er);
-                } else {
-                    const bool hl = box_enter_nopar(nd + 0, nd + 3, sl, el);
-                    const bool hr = box_enter_nopar(nd + 6, nd + 9, sl, er);
-                    okl = hl & (L.t_min >= el);
-                    okr = hr & (L.t_min >= er);
+                double nd[30];
+                row_read<0, 15>(wv, nd);
+                Cand c[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    c[k].ref = k & 1 ? __double2hiint(nd[24 + (k >> 1)]) : __double2loint(nd[24 + (k >> 1)]);
+                    c[k].cnt = k & 1 ? __double2hiint(nd[26 + (k >> 1)]) : __double2loint(nd[26 + (k >> 1)]);
+                    double e;
+                    bool hit;
+                    if (any_par) hit = box_enter(nd + 6 * k, nd + 6 * k + 3, sl, e);
+                    else hit = box_enter_nopar(nd + 6 * k, nd + 6 * k + 3, sl, e);
+                    c[k].e = e;
+                    c[k].ok = hit & (L.t_min >= e) & (c[k].cnt >= 0);
                 }
-                const double da = axis == 0 ? L.rd.x : (axis == 1 ? L.rd.y : L.rd.z);
-                const bool left_near = da >= 0.0;
-                const int nref = left_near ? lref : rref, ncnt = left_near ? lcnt : rcnt;
-                const int fref = left_near ? rref : lref, fcnt = left_near ? rcnt : lcnt;
-                const bool okn = left_near ? okl : okr, okf = left_near ? okr : okl;
-                const double ef = left_near ? er : el;
-                if (okn) {
-                    if (okf && L.sp < RTX_STACK) {
+                // Visit order of the reference: at each binary split the near child first, near =
+                // left iff dir[splitAxis] >= 0 (bvh.cpp:139-147).  Slots 0,1 hang under the left
+                // child (split axisL), slots 2,3 under the right child (axisR), the two pairs
+                // under the node itself (axis0).
+                const int axis0 = __double2loint(nd[28]), axisL = __double2hiint(nd[28]), axisR = __double2loint(nd[29]);
+                const double d0 = axis0 == 0 ? L.rd.x : (axis0 == 1 ? L.rd.y : L.rd.z);
+                const double dl = axisL == 0 ? L.rd.x : (axisL == 1 ? L.rd.y : L.rd.z);
+                const double dr = axisR == 0 ? L.rd.x : (axisR == 1 ? L.rd.y : L.rd.z);
+                // a leaf child occupies the first slot of its pair: nothing to order there
+                cand_swap(c[0], c[1], !(dl >= 0.0) && c[1].cnt >= 0);
+                cand_swap(c[2], c[3], !(dr >= 0.0) && c[3].cnt >= 0);
+                const bool right_first = !(d0 >= 0.0);
+                cand_swap(c[0], c[2], right_first);
+                cand_swap(c[1], c[3], right_first);
+                // c[0..3] is now near -> far.  The nearest passing child is entered; the others
+                // are pushed, farthest first, each with its entry distance for the re-check at pop.
+                const bool any0 = c[0].ok, any1 = any0 | c[1].ok, any2 = any1 | c[2].ok;
+#pragma unroll
+                for (int k = 3; k >= 1; k--) {
+                    const bool earlier = k == 3 ? any2 : (k == 2 ? any1 : any0);
+                    if (c[k].ok && earlier && L.sp < RTX_STACK) {
                         if (L.sp > 0) stk[L.sp - 1] = L.top;
-                        L.top.x = __double2loint(ef); L.top.y = __double2hiint(ef); L.top.z = fref; L.top.w = fcnt;
+                        L.top.x = __double2loint(c[k].e); L.top.y = __double2hiint(c[k].e); L.top.z = c[k].ref; L.top.w = c[k].cnt;
                         L.sp++;
                     }
-                    L.cur_ref = nref; L.cur_cnt = ncnt;
-                } else if (okf) {
-                    L.cur_ref = fref; L.cur_cnt = fcnt;
+                }
+                if (any2 | c[3].ok) {
+                    const int sel = any0 ? 0 : (c[1].ok ? 1 : (c[2].ok ? 2 : 3));
+                    L.cur_ref = sel == 0 ? c[0].ref : (sel == 1 ? c[1].ref : (sel == 2 ? c[2].ref : c[3].ref));
+                    L.cur_cnt = sel == 0 ? c[0].cnt : (sel == 1 ? c[1].cnt : (sel == 2 ? c[2].cnt : c[3].cnt));
                 } else {
                     need_pop = true;
                 }
             } else {
-                // the leaf's next triangle, in leaf order (bvh.cpp:150-170)
+                // ---- leaf: its next two triangles, in leaf order (bvh.cpp:150-170) ----------------
                 const int ti = L.cur_ref;
-                if (COUNT) tl.tri_tests++;
-                double td[14];
-                bool culled = false;
-                if (cull) {
-                    row_read<7>(wv, td);
-                    culled = L.rd.x * td[10] + L.rd.y * td[11] + L.rd.z * td[12] > 0.0;    // utils.cpp:322-326
+                const bool two = L.cur_cnt >= 2;
+                if (COUNT) tl.tri_tests += two ? 2u : 1u;
+                double td[14], tq[14];
+                bool culled0 = false, culled1 = false;
+                if (cull) {                                                                   // utils.cpp:322-326
+                    row_read<0, 7>(wv, td);
+                    row_read<8, 7>(wv, tq);
+                    culled0 = L.rd.x * td[10] + L.rd.y * td[11] + L.rd.z * td[12] > 0.0;
+                    culled1 = L.rd.x * tq[10] + L.rd.y * tq[11] + L.rd.z * tq[12] > 0.0;
                 } else {
-                    row_read<5>(wv, td);
+                    row_read<0, 5>(wv, td);
+                    row_read<8, 5>(wv, tq);
                 }
                 double t, b, g2;
-                if (!culled && tri_test(td, L.ro, L.rd, L.t_min, isect_eps, t, b, g2)) { L.t_min = t; L.btri = ti; }
-                L.cur_ref++; L.cur_cnt--;
-                need_pop = L.cur_cnt == 0;
+                if (!culled0 && tri_test(td, L.ro, L.rd, L.t_min, isect_eps, t, b, g2)) { L.t_min = t; L.btri = ti; }
+                if (two && !culled1 && tri_test(tq, L.ro, L.rd, L.t_min, isect_eps, t, b, g2)) { L.t_min = t; L.btri = ti + 1; }
+                L.cur_ref += 2; L.cur_cnt -= 2;
+                need_pop = L.cur_cnt <= 0;
             }
         }
         __builtin_amdgcn_wave_barrier();
@@ -994,7 +1035,7 @@ k_trace(const Launch* __restrict__ Lp, GenCtrl* ctrl, const int gen, double* __r
     const Scene& S = Lp->S;
     const Frame& F = Lp->F;
     const Queue& qin = Lp->q[(gen + 1) & 1];
-    __shared__ __attribute__((aligned(16))) double lds_rows[4][64 * RTX_ROW_DOUBLES];
+    __shared__ __attribute__((aligned(16))) double lds_rows[4][64 * RTX_ROW_DOUBLES];      // 64 KB per block
     Wave wv;
     wv.rows = (lds_double*)&lds_rows[threadIdx.x >> 6][0];
     wv.lane = lane_id();
