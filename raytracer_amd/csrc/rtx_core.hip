@@ -587,7 +587,7 @@ int rtx_render(rtx_scene* sc, const rtx_camera* cam, int32_t tw, int32_t th, int
     HIP_TRY(sc->accum.ensure((size_t)n_local_px * 3 * sizeof(double)));
     HIP_TRY(sc->rgb.ensure((size_t)n_local_px * 3));
     HIP_TRY(sc->ctrl.ensure((size_t)(G + 1) * sizeof(GenCtrl)));
-    HIP_TRY(sc->counters.ensure(sizeof(Counters)));
+    HIP_TRY(sc->counters.ensure((size_t)G * sizeof(Counters)));      // one block per generation
     if (hit_ids) HIP_TRY(sc->aov.ensure((size_t)cam->width * cam->height * sizeof(rtx_hit_id)));
 
     int dev_cus = 256;
@@ -629,7 +629,7 @@ int rtx_render(rtx_scene* sc, const rtx_camera* cam, int32_t tw, int32_t th, int
 
         HIP_TRY(hipMemsetAsync(sc->ctrl.p, 0, (size_t)(G + 1) * sizeof(GenCtrl), sc->stream));
         HIP_TRY(hipMemsetAsync(sc->accum.p, 0, (size_t)n_local_px * 3 * sizeof(double), sc->stream));
-        if (sc->counters_on) HIP_TRY(hipMemsetAsync(sc->counters.p, 0, sizeof(Counters), sc->stream));
+        if (sc->counters_on) HIP_TRY(hipMemsetAsync(sc->counters.p, 0, (size_t)G * sizeof(Counters), sc->stream));
         // RTX_AMD_GEN_TIMING=1 (development aid): per-generation kernel times on stderr
         static const bool gen_timing = getenv("RTX_AMD_GEN_TIMING") != nullptr;
         std::vector<hipEvent_t> gev;
@@ -645,7 +645,7 @@ int rtx_render(rtx_scene* sc, const rtx_camera* cam, int32_t tw, int32_t th, int
             rtx_hit_id* aov = (gen == 0 && hit_ids) ? (rtx_hit_id*)sc->aov.p : nullptr;
             if (sc->counters_on)
                 hipLaunchKernelGGL(k_trace<true>, dim3(blocks), dim3(256), 0, sc->stream, lp, (GenCtrl*)sc->ctrl.p, gen,
-                                   (double*)sc->accum.p, aov, (Counters*)sc->counters.p);
+                                   (double*)sc->accum.p, aov, (Counters*)sc->counters.p + gen);
             else
                 hipLaunchKernelGGL(k_trace<false>, dim3(blocks), dim3(256), 0, sc->stream, lp, (GenCtrl*)sc->ctrl.p, gen,
                                    (double*)sc->accum.p, aov, (Counters*)nullptr);
@@ -704,8 +704,22 @@ int rtx_render(rtx_scene* sc, const rtx_camera* cam, int32_t tw, int32_t th, int
     else HIP_TRY(hipMemcpyAsync(rgb_out, sc->rgb.p, (size_t)n_local_px * 3, hipMemcpyDeviceToHost, sc->stream));
     if (hit_ids) HIP_TRY(hipMemcpyAsync(hit_ids, sc->aov.p, (size_t)cam->width * cam->height * sizeof(rtx_hit_id), hipMemcpyDeviceToHost, sc->stream));
     Counters ctr{};
-    if (sc->counters_on) HIP_TRY(hipMemcpyAsync(&ctr, sc->counters.p, sizeof ctr, hipMemcpyDeviceToHost, sc->stream));
+    std::vector<Counters> per_gen((size_t)G);
+    if (sc->counters_on) HIP_TRY(hipMemcpyAsync(per_gen.data(), sc->counters.p, per_gen.size() * sizeof(Counters), hipMemcpyDeviceToHost, sc->stream));
     HIP_TRY(hipStreamSynchronize(sc->stream));
+    if (sc->counters_on) {
+        static_assert(sizeof(Counters) % sizeof(unsigned long long) == 0, "Counters is an array of u64");
+        for (const Counters& c : per_gen)
+            for (size_t k = 0; k < sizeof(Counters) / sizeof(unsigned long long); k++)
+                ((unsigned long long*)&ctr)[k] += ((const unsigned long long*)&c)[k];
+        if (getenv("RTX_AMD_GEN_TIMING"))
+            for (int gen = 0; gen < G; gen++) {
+                const Counters& c = per_gen[(size_t)gen];
+                fprintf(stderr, "[rtx] gen %d: %llu rays, %llu wave-steps, %llu service passes; longest wave %.1f us "
+                        "(at 2.4 GHz): %llu steps, %llu service passes\n", gen, c.rays, c.inner_steps + c.leaf_steps,
+                        c.service_passes, (double)c.max_wave_ticks / 2400.0, c.max_wave_steps & 0xFFFFFFFFull, c.max_wave_steps >> 32);
+            }
+    }
     if (sc->counters_on && getenv("RTX_AMD_GEN_TIMING"))
         fprintf(stderr, "[rtx] trace waves %llu: ticks/wave total %.0f traverse %.0f service %.0f; service passes %llu "
                 "(%.0f ticks each), traversal steps %llu (%.0f ticks each; fetch %.0f, pop %.0f)\n", ctr.waves,

@@ -190,6 +190,7 @@ struct Counters {
     unsigned long long inner_steps, inner_lanes, leaf_steps, leaf_lanes;
     // time split of the trace kernel's waves, in shader-clock ticks summed over waves
     unsigned long long service_passes, clk_traverse, clk_service, clk_total, waves, clk_fetch, clk_pop;
+    unsigned long long max_wave_ticks, max_wave_steps;   // longest-lived wave of the launch and its step count (atomic max)
     unsigned long long section[8];   // service sections: ticks summed over lanes (begin, finalize, next job, complete), then call counts
 };
 

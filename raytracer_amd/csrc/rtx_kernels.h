@@ -1050,12 +1050,11 @@ k_trace(const Launch* __restrict__ Lp, GenCtrl* ctrl, const int gen, double* __r
 
     // Rays are claimed in chunks (one atomic per chunk per wave) and handed to lanes as they
     // fall idle.  A thin generation is latency bound: smaller chunks spread it over more waves.
-    unsigned chunk = RTX_CHUNK;
-    if (gen != 0) {
-        const unsigned waves = gridDim.x * (blockDim.x >> 6);
-        chunk = (n_in + waves - 1u) / waves;
-        chunk = chunk < 1u ? 1u : (chunk > RTX_CHUNK ? RTX_CHUNK : chunk);
-    }
+    // Chunks shrink as the generation drains (guided scheduling: a share of what the last claim
+    // saw remaining), so that no wave is left with several rounds of rays when the others run dry.
+    const unsigned n_waves = gridDim.x * (blockDim.x >> 6);
+    unsigned chunk = (n_in + 2u * n_waves - 1u) / (2u * n_waves);
+    chunk = chunk < 1u ? 1u : (chunk > RTX_CHUNK ? RTX_CHUNK : chunk);
     unsigned chunk_next = 0, chunk_end = 0;      // wave-uniform
     bool drained = false;                        // wave-uniform: the generation has no rays left
 
@@ -1085,7 +1084,12 @@ k_trace(const Launch* __restrict__ Lp, GenCtrl* ctrl, const int gen, double* __r
                         if (lane == 0) base = atomicAdd(&me->head_trace, chunk);
                         base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
                         if (base >= n_in) { drained = true; chunk_next = chunk_end = 0; }
-                        else { chunk_next = base; chunk_end = min(base + chunk, n_in); }
+                        else {
+                            chunk_next = base; chunk_end = min(base + chunk, n_in);
+                            const unsigned share = (n_in - chunk_end) / (2u * n_waves);
+                            chunk = share < 16u ? 16u : (share > RTX_CHUNK ? RTX_CHUNK : share);
+                            if (chunk > n_in) chunk = n_in;
+                        }
                     }
                     if (!drained) {
                         const unsigned take = min((unsigned)__popcll(me_), chunk_end - chunk_next);
@@ -1128,17 +1132,22 @@ k_trace(const Launch* __restrict__ Lp, GenCtrl* ctrl, const int gen, double* __r
 
     if (COUNT && counters) {
         const bool l0 = lane == 0;
-        unsigned long long v[28] = {tl.rays, tl.primary, tl.shadow, tl.secondary, tl.node_visits, tl.tri_tests,
+        unsigned long long v[30] = {tl.rays, tl.primary, tl.shadow, tl.secondary, tl.node_visits, tl.tri_tests,
                                     tl.world_box, tl.obj_trav, tl.tlas_visits, tl.inner_steps, tl.inner_lanes,
                                     tl.leaf_steps, tl.leaf_lanes, l0 ? tl.passes : 0u, l0 ? tl.clk_trav : 0ull,
                                     l0 ? tl.clk_serv : 0ull, l0 ? (unsigned long long)(clock64() - clk_begin) : 0ull,
-                                    l0 ? 1ull : 0ull, l0 ? tl.clk_fetch : 0ull, l0 ? tl.clk_pop : 0ull,
+                                    l0 ? 1ull : 0ull, l0 ? tl.clk_fetch : 0ull, l0 ? tl.clk_pop : 0ull, 0ull, 0ull,
                                     tl.sec[0], tl.sec[1], tl.sec[2], tl.sec[3], tl.sec[4], tl.sec[5], tl.sec[6], tl.sec[7]};
 #pragma unroll
-        for (int k = 0; k < 28; k++) {
+        for (int k = 0; k < 30; k++) {
             unsigned long long x = v[k];
             for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off);
             if (lane == 0 && x) atomicAdd(((unsigned long long*)counters) + k, x);
+        }
+        if (lane == 0) {
+            const unsigned long long life = (unsigned long long)(clock64() - clk_begin);
+            const unsigned long long prev = atomicMax(&counters->max_wave_ticks, life);
+            if (life > prev) counters->max_wave_steps = tl.inner_steps + tl.leaf_steps + ((unsigned long long)tl.passes << 32);
         }
     }
 }
