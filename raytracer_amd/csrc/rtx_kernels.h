@@ -137,19 +137,17 @@ RTX_DEV bool box_enter(const double* mn, const double* mx, const Slab& s, double
     return t1 >= t0;
 }
 
-// The same test for a ray with no "parallel" axis (par == 0), written without branches: the
-// per-axis results are selected, not skipped, so a wave executes one straight instruction
-// stream.  Same operations on the same values as box_enter, hence the same bits.
+// The same test for a ray with no "parallel" axis (par == 0), written without branches and
+// with hardware min/max.  With par == 0 every 1/d is finite, so no product is a NaN, and for
+// non-NaN operands "swap if a > b", std::max and std::min are exactly min/max (a zero's sign
+// may differ, which no comparison downstream can see): same values as box_enter.
 RTX_DEV bool box_enter_nopar(const double* mn, const double* mx, const Slab& s, double& enter) {
     const double ax = (mn[0] - s.ox) * s.ix, bx = (mx[0] - s.ox) * s.ix;
     const double ay = (mn[1] - s.oy) * s.iy, by = (mx[1] - s.oy) * s.iy;
     const double az = (mn[2] - s.oz) * s.iz, bz = (mx[2] - s.oz) * s.iz;
-    const bool sx = ax > bx, sy = ay > by, sz = az > bz;
-    const double lox = sx ? bx : ax, hix = sx ? ax : bx;
-    const double loy = sy ? by : ay, hiy = sy ? ay : by;
-    const double loz = sz ? bz : az, hiz = sz ? az : bz;
-    const double t0 = smax(smax(smax(0.0, lox), loy), loz);
-    const double t1 = smin(smin(smin((double)INFINITY, hix), hiy), hiz);
+    const double t0 = __builtin_fmax(__builtin_fmax(__builtin_fmax(0.0, __builtin_fmin(ax, bx)), __builtin_fmin(ay, by)),
+                                     __builtin_fmin(az, bz));
+    const double t1 = __builtin_fmin(__builtin_fmin(__builtin_fmax(ax, bx), __builtin_fmax(ay, by)), __builtin_fmax(az, bz));
     enter = t0;
     return t1 >= t0;
 }
@@ -210,7 +208,7 @@ typedef __attribute__((address_space(1))) v4i glob_v4i;
 struct Wave { lds_double* rows; unsigned lane; };
 
 // Wave-cooperative gather of one 256-byte record per requesting lane into that lane's LDS row.
-// `key` names the record: -1 = no request, otherwise bit 31 clear = BLAS node `key`, bit 31
+// `mask` = ballot of the requesting lanes; `key` names the record: -1 = no request, otherwise bit 31 clear = BLAS node `key`, bit 31
 // set = the pair of triangle records starting at triangle `key & 0x7fffffff`.
 //
 // Sixteen lanes read one record as sixteen adjacent 16-byte pieces, so one load instruction
@@ -224,7 +222,8 @@ struct Wave { lds_double* rows; unsigned lane; };
 // here and to the slot index in row_read.  Must be executed by every lane of the wave.
 typedef __attribute__((address_space(3))) int lds_int;
 typedef __attribute__((address_space(3))) v4i lds_v4i;
-RTX_DEV void coop_fetch(const Wave& wv, int key, const char* __restrict__ nodes, const char* __restrict__ tris) {
+RTX_DEV void coop_fetch(const Wave& wv, unsigned long long mask, int key, const char* __restrict__ nodes,
+                        const char* __restrict__ tris) {
     const unsigned lane = wv.lane, quarter = lane >> 4, slot = lane & 15u;
     ((lds_int*)wv.rows)[(lane & 3u) * 16u + (lane >> 2)] = key;
     __builtin_amdgcn_wave_barrier();
@@ -242,6 +241,8 @@ RTX_DEV void coop_fetch(const Wave& wv, int key, const char* __restrict__ nodes,
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int g = 0; g < 16; g++) {
+        // (wave-uniform skip: in a sparsely occupied wave most rounds have no requester)
+        if (((unsigned)(mask >> (4 * g)) & 0xFu) == 0u) continue;
         const int okey = okeys[g];
         const unsigned piece = slot ^ ((4u * g + quarter) & 15u);
         if (okey != -1) {
@@ -456,6 +457,7 @@ RTX_DEV void tlas_collect(const Scene& S, const Slab& sl, double t_min, int last
 enum { LS_EMPTY = 0, LS_NEED_JOB = 1, LS_JOB_DONE = 2, LS_IN_JOB = 3 };
 
 #define RTX_SERVICE_THRESHOLD 24     // lanes waiting for service that trigger a service pass
+#define RTX_SPARSE_LANES 2           // at most this many traversing lanes: load records directly
 #define RTX_CHUNK 256                // rays a wave claims per atomic
 #ifndef RTX_TRACE_WAVES
 #define RTX_TRACE_WAVES 2            // waves per SIMD the trace kernel is compiled for (2: 256 VGPRs)
@@ -920,8 +922,24 @@ RTX_DEV void traverse_steps(const Scene& S, const Wave& wv, Lane& L, glob_v4i* _
         // only when one of its traversing lanes has one
         const bool any_par = __ballot(in_job && L.par != 0) != 0ull;
 
+        // The lane's 256-byte record: a collapsed node, or two consecutive triangle records.
+        // A wave with only a lane or two still traversing is on the frame's critical path (the
+        // longest rays of a generation); it loads the records directly, one memory round trip
+        // without the detour through LDS.  Otherwise the wave fetches cooperatively.
         const long long f0 = COUNT ? clock64() : 0;
-        coop_fetch(wv, in_job ? (at_leaf ? (L.cur_ref | (int)0x80000000) : L.cur_ref) : -1, nodes, tris);
+        double rec[32];
+        if (__popcll(m_job) <= RTX_SPARSE_LANES) {
+            if (in_job) {
+                const RTX_GLOBAL v2d* gp = (const RTX_GLOBAL v2d*)(at_leaf ? tris + (size_t)(unsigned)L.cur_ref * sizeof(Tri)
+                                                                           : nodes + (size_t)(unsigned)L.cur_ref * sizeof(Node4));
+#pragma unroll
+                for (int p = 0; p < 16; p++) { const v2d v = gp[p]; rec[2 * p] = v.x; rec[2 * p + 1] = v.y; }
+            }
+        } else {
+            coop_fetch(wv, m_job, in_job ? (at_leaf ? (L.cur_ref | (int)0x80000000) : L.cur_ref) : -1, nodes, tris);
+            if (in_job) row_read<0, 16>(wv, rec);
+            __builtin_amdgcn_wave_barrier();
+        }
         if (COUNT) tl.clk_fetch += (unsigned long long)(clock64() - f0);
 
         bool need_pop = false;
@@ -929,8 +947,7 @@ RTX_DEV void traverse_steps(const Scene& S, const Wave& wv, Lane& L, glob_v4i* _
             if (!at_leaf) {
                 // ---- collapsed inner node: up to four grandchildren of a binary node ------------
                 if (COUNT) tl.node_visits++;
-                double nd[30];
-                row_read<0, 15>(wv, nd);
+                const double* nd = rec;
                 Cand c[4];
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
@@ -981,16 +998,12 @@ RTX_DEV void traverse_steps(const Scene& S, const Wave& wv, Lane& L, glob_v4i* _
                 const int ti = L.cur_ref;
                 const bool two = L.cur_cnt >= 2;
                 if (COUNT) tl.tri_tests += two ? 2u : 1u;
-                double td[14], tq[14];
+                const double* td = rec;
+                const double* tq = rec + 16;
                 bool culled0 = false, culled1 = false;
                 if (cull) {                                                                   // utils.cpp:322-326
-                    row_read<0, 7>(wv, td);
-                    row_read<8, 7>(wv, tq);
                     culled0 = L.rd.x * td[10] + L.rd.y * td[11] + L.rd.z * td[12] > 0.0;
                     culled1 = L.rd.x * tq[10] + L.rd.y * tq[11] + L.rd.z * tq[12] > 0.0;
-                } else {
-                    row_read<0, 5>(wv, td);
-                    row_read<8, 5>(wv, tq);
                 }
                 double t, b, g2;
                 if (!culled0 && tri_test(td, L.ro, L.rd, L.t_min, isect_eps, t, b, g2)) { L.t_min = t; L.btri = ti; }
