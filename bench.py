@@ -33,20 +33,48 @@ sys.path.insert(0, ROOT)
 
 import numpy as np  # noqa: E402
 
-# Device-layout record sizes (raytracer_amd/csrc/rtx_device_types.h): what one unit of
-# traversal work has to read, used for the algorithmic-bytes figure of the roofline.
-NODE_BYTES = 128      # one inner-node visit = both children's boxes + links
-TRI_BYTES = 72        # one triangle test = (a, e1, e2)
-BOX_BYTES = 48        # one world-AABB test
-XFORM_BYTES = 128     # one ray taken to object space = the inverse matrix
-RAY_BYTES = 88        # one queue item (written once, read once)
+# Algorithmic traffic of one frame, in the reference's own in-memory record sizes: what the
+# reference's traversal has to read per unit of work, whatever layout the device uses.
+#   72 B  one BVH node whose box is tested           (sizeof(BVHNode), bvh.h:50-61)
+#   88 B  one triangle test                          (4 B faceIndices + 12 B face + 3 x 24 B vertices)
+#   48 B  one world-space AABB test                  (AABB, bvh.h:11-16)
+#  128 B  one ray taken to object space              (one Matrix4x4, scene.h:123-128)
+#  384 B  one accepted back-transformed hit          (three Matrix4x4)
+#   96 B  per ray                                    (ray in + hit record out)
+# The work counts are those of the reference's algorithm, produced by its CPU restatement
+# (oracle/rt_oracle.c) in an untimed pass; the device's own ray and triangle-test counters must
+# agree with them (reported as "counters_agree").
 HBM_PEAK_GBS = 8000.0
 
 
-def algorithmic_bytes(st) -> int:
-    return (NODE_BYTES * st["node_visits"] + TRI_BYTES * st["tri_tests"] + BOX_BYTES * st["world_box_tests"]
-            + XFORM_BYTES * st["object_space_traversals"] + NODE_BYTES * st["tlas_node_visits"]
-            + 2 * RAY_BYTES * (st["rays"] - st["primary_rays"]) + 24 * st["primary_rays"])
+class OracleCounters(C.Structure):
+    _fields_ = [(k, C.c_uint64) for k in ("rays", "primary_rays", "shadow_rays", "secondary_rays", "node_pops",
+                                          "tri_tests", "world_box_tests", "ray_transforms", "transformed_hits",
+                                          "shades")]
+
+
+def algorithmic_bytes(c) -> int:
+    return (72 * c["node_pops"] + 88 * c["tri_tests"] + 48 * c["world_box_tests"] + 128 * c["ray_transforms"]
+            + 384 * c["transformed_hits"] + 96 * c["rays"])
+
+
+def reference_work_counts(desc, cam, nthreads):
+    """Work counters of the reference's algorithm for one frame, from its CPU restatement
+    (untimed; None when the checker library is not built)."""
+    so = os.path.join(ROOT, "oracle", "librt_oracle.so")
+    if not os.path.exists(so):
+        return None, None
+    from raytracer_amd import _abi
+    lib = C.CDLL(so)
+    lib.rt_oracle_render.argtypes = [C.POINTER(_abi.SceneDesc), C.POINTER(_abi.Camera), C.c_void_p, C.c_void_p,
+                                     C.POINTER(OracleCounters), C.c_int]
+    lib.rt_oracle_render.restype = C.c_double
+    rgb = np.empty((cam.height, cam.width, 3), dtype=np.uint8)
+    ctr = OracleCounters()
+    ms = lib.rt_oracle_render(desc, C.byref(cam), rgb.ctypes.data, None, C.byref(ctr), nthreads)
+    if ms < 0:
+        return None, None
+    return {k: int(getattr(ctr, k)) for k, _ in OracleCounters._fields_}, ms
 
 
 def scene_cache_dir():
@@ -201,7 +229,25 @@ def main():
         _, cst = ds.render_tiles(cam, tw, th, rank, world)
     ds.set_counters(False)
     rays_rank = int(cst["rays"])
-    alg_bytes_rank = algorithmic_bytes(cst)
+    host_threads = max(1, min(16, os.cpu_count() or 1) // max(world, 1)) if world > 1 else min(16, os.cpu_count() or 1)
+    ref_counts, oracle_ms = (None, None)
+    if args.mode == "frames":
+        ref_counts, oracle_ms = reference_work_counts(hs.desc, cam, host_threads)
+    if ref_counts is not None:
+        # (world-box tests are not compared: the device's TLAS rejects most instances before
+        # their boxes are tested, the reference tests every instance's box, utils.cpp:756-766)
+        counters_agree = ref_counts["rays"] == cst["rays"] and ref_counts["tri_tests"] == cst["tri_tests"]
+        alg_bytes_rank = algorithmic_bytes(ref_counts)
+        alg_source = "reference algorithm's work counts (CPU restatement, untimed pass) x reference record sizes"
+    else:
+        # tiles mode / checker not built: the device's counters, a collapsed-node visit priced as the
+        # three binary nodes it stands for at most
+        counters_agree = None
+        alg_bytes_rank = algorithmic_bytes({"node_pops": 3 * cst["node_visits"], "tri_tests": cst["tri_tests"],
+                                            "world_box_tests": cst["world_box_tests"],
+                                            "ray_transforms": cst["object_space_traversals"],
+                                            "transformed_hits": 0, "rays": cst["rays"]})
+        alg_source = "device counters (estimate)"
 
     frame = np.empty((cam.height, cam.width, 3), dtype=np.uint8)
     gather_buf = None
@@ -231,9 +277,13 @@ def main():
     barrier()
     t0 = time.perf_counter()
     kernel_ms = 0.0
+    trace_ms = 0.0
+    trace_launches = 0
     for _ in range(args.steps):
         st = step()
         kernel_ms += st["kernel_ms"]
+        trace_ms += st["trace_ms"]
+        trace_launches += st["trace_launches"]
     barrier()
     elapsed = time.perf_counter() - t0
 
@@ -248,9 +298,14 @@ def main():
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         mrays = rays_step * args.steps / elapsed / 1e6
-        G = hs.desc.contents.max_recursion_depth + 2
-        k_ms_frame = kernel_ms / args.steps                    # rank 0's frame, all k_trace launches
-        achieved = alg_bytes_rank / (k_ms_frame * 1e-3) / 1e9 if k_ms_frame > 0 else 0.0
+        # Dominant kernel: k_trace, one launch per ray generation.  Its launches are bracketed by HIP
+        # events on the library's own stream (rtx_stats.trace_ms / trace_launches).  A launch
+        # processes, on average, 1/launches_per_frame of the frame's algorithmic bytes.
+        launches_per_frame = trace_launches / args.steps
+        avg_launch_ms = trace_ms / max(trace_launches, 1)
+        bytes_per_launch = alg_bytes_rank / max(launches_per_frame, 1)
+        achieved = bytes_per_launch / (avg_launch_ms * 1e-3) / 1e9 if avg_launch_ms > 0 else 0.0
+        k_ms_frame = kernel_ms / args.steps                    # every kernel of rank 0's frame
         traffic = None
         tfile = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tfile):
@@ -273,14 +328,19 @@ def main():
                        "host_load_s": t_load, "scene_upload_s": t_upload},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "k_trace", "launches_per_frame": G,
-                         "avg_launch_ms": k_ms_frame / G, "kernel_ms_per_frame": k_ms_frame,
-                         "algorithmic_bytes_per_launch": alg_bytes_rank / G,
+                         "kernel": "k_trace", "launches_per_frame": launches_per_frame,
+                         "avg_launch_ms": avg_launch_ms, "trace_ms_per_frame": trace_ms / args.steps,
+                         "all_kernels_ms_per_frame": k_ms_frame,
+                         "algorithmic_bytes_per_launch": bytes_per_launch,
+                         "algorithmic_bytes_per_frame": alg_bytes_rank,
                          "algorithmic_bytes_per_ray": alg_bytes_rank / max(rays_rank, 1),
-                         "node_visits": int(cst["node_visits"]), "tri_tests": int(cst["tri_tests"]),
-                         "simt_lanes_per_inner_step": cst["wave_inner_lanes"] / max(cst["wave_inner_steps"], 1),
-                         "simt_lanes_per_leaf_step": cst["wave_leaf_lanes"] / max(cst["wave_leaf_steps"], 1),
-                         "wave_inner_steps": int(cst["wave_inner_steps"]), "wave_leaf_steps": int(cst["wave_leaf_steps"])},
+                         "algorithmic_source": alg_source, "counters_agree": counters_agree,
+                         "reference_work_counts": ref_counts,
+                         "device_record_visits": int(cst["node_visits"]), "tri_tests": int(cst["tri_tests"]),
+                         "lanes_at_nodes_per_wave_step": cst["wave_inner_lanes"] / max(cst["wave_inner_steps"], 1),
+                         "lanes_at_leaves_per_wave_step": cst["wave_leaf_lanes"] / max(cst["wave_leaf_steps"], 1),
+                         "wave_steps_with_node_lanes": int(cst["wave_inner_steps"]),
+                         "wave_steps_with_leaf_lanes": int(cst["wave_leaf_steps"])},
         }
         if world == 1 and not args.no_cpu_baseline:
             cb = cpu_reference_baseline(path, rays_rank)

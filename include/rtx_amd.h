@@ -140,7 +140,7 @@ typedef struct rtx_hit_id { int32_t kind, container, face, src; double distance;
  * computePixelColor discards because depth > maxRecursionDepth (utils.cpp:1047). */
 typedef struct rtx_stats {
     uint64_t rays, primary_rays, shadow_rays, secondary_rays;
-    uint64_t node_visits;      /* BLAS inner-node visits (two child boxes fetched each)    */
+    uint64_t node_visits;      /* BLAS record visits (one record = two binary BVH levels) */
     uint64_t tri_tests;        /* rayHitsTriangle evaluations                             */
     uint64_t world_box_tests;  /* per-object world-AABB tests (utils.cpp:451,761)         */
     uint64_t object_space_traversals;
@@ -151,6 +151,11 @@ typedef struct rtx_stats {
     /* SIMT occupancy of the traversal (counters on): wave-level inner-node / triangle steps
      * and the number of lanes that did useful work in them (64 per step is the ideal). */
     uint64_t wave_inner_steps, wave_inner_lanes, wave_leaf_steps, wave_leaf_lanes;
+    /* The dominant kernel (closest-hit traversal, one launch per ray generation): summed HIP-event
+     * duration of its launches and their number (a frame redone after a queue overflow counts
+     * both attempts). */
+    double trace_ms;
+    uint32_t trace_launches, pad;
 } rtx_stats;
 
 typedef struct rtx_scene rtx_scene;   /* opaque: owns the device copy of the scene */

@@ -65,6 +65,7 @@ struct rtx_scene {
     int device = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::vector<hipEvent_t> gen_events;   // 2 per generation + 1: brackets of the trace launches
     Scene dev{};                    // kernel argument (device pointers inside)
     int n_meshes = 0;
     bool counters_on = false;
@@ -74,6 +75,7 @@ struct rtx_scene {
         tlas, tlas_order;
     DevBuf accum, rgb, aov, ctrl, counters, queue[2], hitbuf, launch, stacks;
     ~rtx_scene() {
+        for (hipEvent_t e : gen_events) (void)hipEventDestroy(e);
         if (ev0) (void)hipEventDestroy(ev0);
         if (ev1) (void)hipEventDestroy(ev1);
         if (stream) (void)hipStreamDestroy(stream);
@@ -604,7 +606,8 @@ int rtx_render(rtx_scene* sc, const rtx_camera* cam, int32_t tw, int32_t th, int
         sc->queue_capacity = (uint32_t)std::min<int64_t>(want, 0x7FFFFFF0);
     }
     uint32_t overflows = 0;
-    float kernel_ms = 0.f;
+    float kernel_ms = 0.f, trace_ms = 0.f;
+    uint32_t trace_launches = 0;
     while (true) {
         if ((int64_t)sc->queue_capacity * (int64_t)kRayBytes * 2 > sc->queue_limit) {
             uint32_t cap = (uint32_t)(sc->queue_limit / (2 * (int64_t)kRayBytes));
@@ -632,14 +635,16 @@ int rtx_render(rtx_scene* sc, const rtx_camera* cam, int32_t tw, int32_t th, int
         if (sc->counters_on) HIP_TRY(hipMemsetAsync(sc->counters.p, 0, (size_t)G * sizeof(Counters), sc->stream));
         // RTX_AMD_GEN_TIMING=1 (development aid): per-generation kernel times on stderr
         static const bool gen_timing = getenv("RTX_AMD_GEN_TIMING") != nullptr;
-        std::vector<hipEvent_t> gev;
-        if (gen_timing) {
-            gev.resize((size_t)2 * G + 1);
-            for (hipEvent_t& e : gev) HIP_TRY(hipEventCreate(&e));
+        // every trace launch is bracketed by events: rtx_stats.trace_ms is the sum of their durations
+        while (sc->gen_events.size() < (size_t)2 * G + 1) {
+            hipEvent_t e;
+            HIP_TRY(hipEventCreate(&e));
+            sc->gen_events.push_back(e);
         }
+        std::vector<hipEvent_t>& gev = sc->gen_events;
         HIP_TRY(hipEventRecord(sc->ev0, sc->stream));
         for (int gen = 0; gen < G; gen++) {
-            if (gen_timing) HIP_TRY(hipEventRecord(gev[2 * gen], sc->stream));
+            HIP_TRY(hipEventRecord(gev[2 * gen], sc->stream));
             unsigned blocks = persistent_blocks;
             if (gen == 0) blocks = (unsigned)std::min<int64_t>(persistent_blocks, (n_items0 + 255) / 256);
             rtx_hit_id* aov = (gen == 0 && hit_ids) ? (rtx_hit_id*)sc->aov.p : nullptr;
@@ -649,7 +654,7 @@ int rtx_render(rtx_scene* sc, const rtx_camera* cam, int32_t tw, int32_t th, int
             else
                 hipLaunchKernelGGL(k_trace<false>, dim3(blocks), dim3(256), 0, sc->stream, lp, (GenCtrl*)sc->ctrl.p, gen,
                                    (double*)sc->accum.p, aov, (Counters*)nullptr);
-            if (gen_timing) HIP_TRY(hipEventRecord(gev[2 * gen + 1], sc->stream));
+            HIP_TRY(hipEventRecord(gev[2 * gen + 1], sc->stream));
             // the last generation holds shadow rays only: nothing left to shade
             if (gen + 1 < G)
                 hipLaunchKernelGGL(k_shade, dim3(blocks), dim3(256), 0, sc->stream, lp, (GenCtrl*)sc->ctrl.p, gen,
@@ -658,7 +663,7 @@ int rtx_render(rtx_scene* sc, const rtx_camera* cam, int32_t tw, int32_t th, int
         const unsigned n_values = (unsigned)(n_local_px * 3);
         hipLaunchKernelGGL(k_resolve, dim3((n_values + 255) / 256), dim3(256), 0, sc->stream,
                            (const double*)sc->accum.p, (uint8_t*)sc->rgb.p, n_values);
-        if (gen_timing) HIP_TRY(hipEventRecord(gev[2 * G], sc->stream));
+        HIP_TRY(hipEventRecord(gev[2 * G], sc->stream));
         HIP_TRY(hipEventRecord(sc->ev1, sc->stream));
         HIP_TRY(hipGetLastError());
         std::vector<GenCtrl> ctrl((size_t)G + 1);
@@ -667,6 +672,12 @@ int rtx_render(rtx_scene* sc, const rtx_camera* cam, int32_t tw, int32_t th, int
         float ms = 0.f;
         HIP_TRY(hipEventElapsedTime(&ms, sc->ev0, sc->ev1));
         kernel_ms += ms;
+        for (int gen = 0; gen < G; gen++) {
+            float t = 0.f;
+            HIP_TRY(hipEventElapsedTime(&t, gev[2 * gen], gev[2 * gen + 1]));
+            trace_ms += t;
+        }
+        trace_launches += (uint32_t)G;
         if (gen_timing) {
             for (int gen = 0; gen < G; gen++) {
                 float t_trace = 0.f, t_shade = 0.f;
@@ -677,7 +688,6 @@ int rtx_render(rtx_scene* sc, const rtx_camera* cam, int32_t tw, int32_t th, int
                 fprintf(stderr, "[rtx] gen %d: radiance %u shadow %u trace %.1f us shade(+resolve) %.1f us\n", gen,
                         (unsigned)c, (unsigned)(c >> 32), t_trace * 1e3, t_shade * 1e3);
             }
-            for (hipEvent_t& e : gev) (void)hipEventDestroy(e);
         }
         bool overflow = false;
         uint32_t peak = 0;
@@ -743,6 +753,7 @@ int rtx_render(rtx_scene* sc, const rtx_camera* cam, int32_t tw, int32_t th, int
         stats->wave_inner_steps = ctr.inner_steps; stats->wave_inner_lanes = ctr.inner_lanes;
         stats->wave_leaf_steps = ctr.leaf_steps; stats->wave_leaf_lanes = ctr.leaf_lanes;
         stats->kernel_ms = kernel_ms;
+        stats->trace_ms = trace_ms; stats->trace_launches = trace_launches;
         stats->total_ms = std::chrono::duration<double, std::milli>(std::chrono::high_resolution_clock::now() - wall0).count();
     }
     return RTX_OK;

@@ -913,10 +913,12 @@ RTX_DEV void traverse_steps(const Scene& S, const Wave& wv, Lane& L, glob_v4i* _
         const unsigned long long m_wait = __ballot(L.state == LS_NEED_JOB || L.state == LS_JOB_DONE ||
                                                    (refillable && L.state == LS_EMPTY));
         if (__popcll(m_wait) >= RTX_SERVICE_THRESHOLD) break;
-        if (COUNT && lane == 0) {
+        if (COUNT) {
             const int nl = __popcll(__ballot(at_leaf)), nj = __popcll(m_job);
-            if (nj > nl) { tl.inner_steps++; tl.inner_lanes += (unsigned)(nj - nl); }
-            if (nl) { tl.leaf_steps++; tl.leaf_lanes += (unsigned)nl; }
+            if (lane == 0) {
+                if (nj > nl) { tl.inner_steps++; tl.inner_lanes += (unsigned)(nj - nl); }
+                if (nl) { tl.leaf_steps++; tl.leaf_lanes += (unsigned)nl; }
+            }
         }
         // rays with an axis-parallel component are rare: the wave takes the general box test
         // only when one of its traversing lanes has one
