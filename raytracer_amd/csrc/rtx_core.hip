@@ -728,6 +728,9 @@ int rtx_render(rtx_scene* sc, const rtx_camera* cam, int32_t tw, int32_t th, int
                 fprintf(stderr, "[rtx] gen %d: %llu rays, %llu wave-steps, %llu service passes; longest wave %.1f us "
                         "(at 2.4 GHz): %llu steps, %llu service passes\n", gen, c.rays, c.inner_steps + c.leaf_steps,
                         c.service_passes, (double)c.max_wave_ticks / 2400.0, c.max_wave_steps & 0xFFFFFFFFull, c.max_wave_steps >> 32);
+                fprintf(stderr, "[rtx]        rays by steps (<16 <32 <64 <128 <256 <512 <1024 more): %llu %llu %llu %llu %llu %llu %llu %llu\n",
+                        c.ray_steps_hist[0], c.ray_steps_hist[1], c.ray_steps_hist[2], c.ray_steps_hist[3], c.ray_steps_hist[4],
+                        c.ray_steps_hist[5], c.ray_steps_hist[6], c.ray_steps_hist[7]);
             }
     }
     if (sc->counters_on && getenv("RTX_AMD_GEN_TIMING"))

@@ -192,6 +192,7 @@ struct Counters {
     unsigned long long service_passes, clk_traverse, clk_service, clk_total, waves, clk_fetch, clk_pop;
     unsigned long long max_wave_ticks, max_wave_steps;   // longest-lived wave of the launch and its step count (atomic max)
     unsigned long long section[8];   // service sections: ticks summed over lanes (begin, finalize, next job, complete), then call counts
+    unsigned long long ray_steps_hist[8];   // rays by traversal steps: < 16, < 32, ..., < 1024, >= 1024
 };
 
 }  // namespace rtxdev

@@ -186,7 +186,8 @@ struct Tally { unsigned node_visits, tri_tests, world_box, obj_trav, tlas_visits
                unsigned rays, primary, shadow, secondary;
                unsigned passes;                                                  // service passes (lane 0)
                unsigned long long clk_trav, clk_serv, clk_total, clk_fetch, clk_pop;
-               unsigned long long sec[8]; };   // per-lane section profile of service_lane: ticks (0-3), calls (4-7)              // shader-clock ticks (lane 0)
+               unsigned long long sec[8];
+               unsigned hist[8]; };   // per-lane section profile of service_lane: ticks (0-3), calls (4-7)              // shader-clock ticks (lane 0)
 
 #define RTX_STACK 100                // BLAS traversal stack entries per lane (BVH depth <= 64)
 #define RTX_TLAS_STACK 48
@@ -479,6 +480,7 @@ struct Lane {
     int par;
     int cur_ref, cur_cnt, sp, btri;
     int state;
+    int age;                // traversal steps spent on the current ray (maintained when counters are on)
     v4i top;                // top stack entry (valid while sp > 0)
 };
 
@@ -526,7 +528,7 @@ RTX_DEV void ray_begin(const Scene& S, Lane& L, const RecOut& out, Tally& tl) {
         }
         L.hit = hit ? 1 : 0;
     }
-    L.it = 0; L.last = -1; L.more = 0;
+    L.it = 0; L.last = -1; L.more = 0; L.age = 0;
 #pragma unroll
     for (int k = 0; k < RTX_CAND; k++) L.buf[k] = INT_MAX;
     L.state = LS_NEED_JOB;
@@ -860,7 +862,13 @@ RTX_DEV void service_lane(const Launch* __restrict__ Lp, const int gen, double* 
         out.rec->code = hit ? 1 : -1;
     }
     L.state = LS_EMPTY;
-    if (COUNT) { tl.sec[3] += (unsigned long long)(clock64() - c0); tl.sec[7]++; }
+    if (COUNT) {
+        tl.sec[3] += (unsigned long long)(clock64() - c0); tl.sec[7]++;
+        // ray length histogram: < 16, < 32, ... < 1024, >= 1024 steps
+        int b = 0;
+        for (int a = L.age >> 4; a > 0 && b < 7; a >>= 1) b++;
+        tl.hist[b]++;
+    }
 }
 
 // The traversal loop: runs cooperative steps for the lanes that are inside a job until the
@@ -946,6 +954,7 @@ RTX_DEV void traverse_steps(const Scene& S, const Wave& wv, Lane& L, glob_v4i* _
 
         bool need_pop = false;
         if (in_job) {
+            if (COUNT) L.age++;
             if (!at_leaf) {
                 // ---- collapsed inner node: up to four grandchildren of a binary node ------------
                 if (COUNT) tl.node_visits++;
@@ -1147,14 +1156,15 @@ k_trace(const Launch* __restrict__ Lp, GenCtrl* ctrl, const int gen, double* __r
 
     if (COUNT && counters) {
         const bool l0 = lane == 0;
-        unsigned long long v[30] = {tl.rays, tl.primary, tl.shadow, tl.secondary, tl.node_visits, tl.tri_tests,
+        unsigned long long v[38] = {tl.rays, tl.primary, tl.shadow, tl.secondary, tl.node_visits, tl.tri_tests,
                                     tl.world_box, tl.obj_trav, tl.tlas_visits, tl.inner_steps, tl.inner_lanes,
                                     tl.leaf_steps, tl.leaf_lanes, l0 ? tl.passes : 0u, l0 ? tl.clk_trav : 0ull,
                                     l0 ? tl.clk_serv : 0ull, l0 ? (unsigned long long)(clock64() - clk_begin) : 0ull,
                                     l0 ? 1ull : 0ull, l0 ? tl.clk_fetch : 0ull, l0 ? tl.clk_pop : 0ull, 0ull, 0ull,
-                                    tl.sec[0], tl.sec[1], tl.sec[2], tl.sec[3], tl.sec[4], tl.sec[5], tl.sec[6], tl.sec[7]};
+                                    tl.sec[0], tl.sec[1], tl.sec[2], tl.sec[3], tl.sec[4], tl.sec[5], tl.sec[6], tl.sec[7],
+                                    tl.hist[0], tl.hist[1], tl.hist[2], tl.hist[3], tl.hist[4], tl.hist[5], tl.hist[6], tl.hist[7]};
 #pragma unroll
-        for (int k = 0; k < 30; k++) {
+        for (int k = 0; k < 38; k++) {
             unsigned long long x = v[k];
             for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off);
             if (lane == 0 && x) atomicAdd(((unsigned long long*)counters) + k, x);
