@@ -71,7 +71,7 @@ struct rtx_scene {
     bool counters_on = false;
     int64_t queue_limit = (int64_t)32 << 30;
     uint32_t queue_capacity = 0;    // rays per queue, grows on overflow and is then kept
-    DevBuf materials, lights, xforms, planes, spheres, ftris, meshes, insts, objs, nodes, tris, tri_vn,
+    DevBuf materials, lights, xforms, planes, spheres, ftris, meshes, insts, objs, blas, tri_vn,
         tlas, tlas_order;
     DevBuf accum, rgb, aov, ctrl, counters, queue[2], hitbuf, launch, stacks;
     ~rtx_scene() {
@@ -348,6 +348,13 @@ int build_scene(rtx_scene& sc, const rtx_scene_desc& d) {
     }
     if (F.tris.size() > (size_t)INT_MAX / 2) return fail(RTX_ELIMIT, "too many triangles");
     { Tri pad_tri; memset(&pad_tri, 0, sizeof pad_tri); F.tris.push_back(pad_tri); }   // leaf steps fetch triangles in pairs
+    // record indices -> keys (offsets in 128-byte units into the joint node + triangle allocation)
+    if (2 * F.nodes.size() + F.tris.size() > (size_t)INT_MAX) return fail(RTX_ELIMIT, "BLAS larger than 256 GB");
+    const int32_t tri_key0 = (int32_t)(2 * F.nodes.size());
+    auto to_key = [&](int32_t& ref, int32_t cnt) { if (cnt > 0) ref += tri_key0; else if (cnt == 0) ref *= 2; };
+    for (Node4& n : F.nodes) for (int k = 0; k < 4; k++) to_key(n.ref[k], n.cnt[k]);
+    for (Mesh& m : F.meshes) if (m.n_faces > 0) to_key(m.root_ref, m.root_count);
+    S.tri_key0 = tri_key0;
 
     // instances: effective transform (utils.cpp:418,446,476) and TLAS over their world boxes
     std::vector<Inst> insts((size_t)d.n_instances);
@@ -417,8 +424,13 @@ int build_scene(rtx_scene& sc, const rtx_scene_desc& d) {
     HIP_TRY(sc.ftris.upload(ftris));      S.ftris = (const FreeTri*)sc.ftris.p;
     HIP_TRY(sc.meshes.upload(F.meshes));  S.meshes = (const Mesh*)sc.meshes.p;
     HIP_TRY(sc.insts.upload(insts));      S.insts = (const Inst*)sc.insts.p;
-    HIP_TRY(sc.nodes.upload(F.nodes));    S.nodes = (const Node4*)sc.nodes.p;
-    HIP_TRY(sc.tris.upload(F.tris));      S.tris = (const Tri*)sc.tris.p;
+    {
+        const size_t nb = F.nodes.size() * sizeof(Node4), tb = F.tris.size() * sizeof(Tri);
+        HIP_TRY(sc.blas.ensure(nb + tb));
+        if (nb) HIP_TRY(hipMemcpy(sc.blas.p, F.nodes.data(), nb, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy((char*)sc.blas.p + nb, F.tris.data(), tb, hipMemcpyHostToDevice));
+        S.blas = (const char*)sc.blas.p;
+    }
     if (F.any_vn) { HIP_TRY(sc.tri_vn.upload(F.tri_vn)); S.tri_vn = (const double*)sc.tri_vn.p; }
     else {
         // no smooth mesh: keep has_vn = 0 everywhere, nothing to upload
@@ -728,9 +740,16 @@ int rtx_render(rtx_scene* sc, const rtx_camera* cam, int32_t tw, int32_t th, int
                 fprintf(stderr, "[rtx] gen %d: %llu rays, %llu wave-steps, %llu service passes; longest wave %.1f us "
                         "(at 2.4 GHz): %llu steps, %llu service passes\n", gen, c.rays, c.inner_steps + c.leaf_steps,
                         c.service_passes, (double)c.max_wave_ticks / 2400.0, c.max_wave_steps & 0xFFFFFFFFull, c.max_wave_steps >> 32);
+                const double nst = (double)std::max(1ull, c.inner_steps + c.leaf_steps);
+                fprintf(stderr, "[rtx]        ticks per wave-step: %.0f (fetch %.0f, pop %.0f); per service pass: %.0f\n",
+                        (double)c.clk_traverse / nst, (double)c.clk_fetch / nst, (double)c.clk_pop / nst,
+                        (double)c.clk_service / std::max(1ull, c.service_passes));
                 fprintf(stderr, "[rtx]        rays by steps (<16 <32 <64 <128 <256 <512 <1024 more): %llu %llu %llu %llu %llu %llu %llu %llu\n",
                         c.ray_steps_hist[0], c.ray_steps_hist[1], c.ray_steps_hist[2], c.ray_steps_hist[3], c.ray_steps_hist[4],
                         c.ray_steps_hist[5], c.ray_steps_hist[6], c.ray_steps_hist[7]);
+                fprintf(stderr, "[rtx]        of which shadow rays: %llu %llu %llu %llu %llu %llu %llu %llu\n",
+                        c.shadow_steps_hist[0], c.shadow_steps_hist[1], c.shadow_steps_hist[2], c.shadow_steps_hist[3],
+                        c.shadow_steps_hist[4], c.shadow_steps_hist[5], c.shadow_steps_hist[6], c.shadow_steps_hist[7]);
             }
     }
     if (sc->counters_on && getenv("RTX_AMD_GEN_TIMING"))

@@ -21,7 +21,8 @@ namespace rtxdev {
 // Slots 0,1 belong to the left child of the binary node the record stands for, slots 2,3 to its
 // right child: an inner child contributes its own two children, a leaf child sits in the first
 // slot of its pair and leaves the second empty.  cnt: 0 = inner (ref = Node4 index),
-// > 0 = leaf owning triangles [ref, ref + cnt) of the triangle array, -1 = empty slot.
+// > 0 = leaf owning the cnt triangle records from ref on, -1 = empty slot.  ref is a record key
+// (offset in 128-byte units, see Scene::blas).
 // axis0 / axisL / axisR are BVHNode::splitAxis of the binary node, its left and its right child:
 // the near side of a split is the left one iff dir[axis] >= 0 (bvh.cpp:139-147).
 struct alignas(16) Node4 {
@@ -115,8 +116,11 @@ struct Scene {
     const Mesh* meshes;
     const Inst* insts;
     const Obj* objs;          // n_meshes + n_insts records
-    const Node4* nodes;
-    const Tri* tris;
+    // BLAS records: all Node4 records, then all Tri records, in one allocation.  A record is
+    // named by its offset in 128-byte units ("key"): node i has key 2i, triangle j has key
+    // tri_key0 + j.  Child refs in Node4 and root refs in Obj are keys.
+    const char* blas;
+    int32_t tri_key0, pad_blas;
     const double* tri_vn;     // RTX_VN_STRIDE per triangle (vertex normals of its corners) or null
     const TlasNode* tlas;
     const int32_t* tlas_order;
@@ -193,6 +197,7 @@ struct Counters {
     unsigned long long max_wave_ticks, max_wave_steps;   // longest-lived wave of the launch and its step count (atomic max)
     unsigned long long section[8];   // service sections: ticks summed over lanes (begin, finalize, next job, complete), then call counts
     unsigned long long ray_steps_hist[8];   // rays by traversal steps: < 16, < 32, ..., < 1024, >= 1024
+    unsigned long long shadow_steps_hist[8]; // the shadow rays among them
 };
 
 }  // namespace rtxdev

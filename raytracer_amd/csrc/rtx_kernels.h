@@ -187,7 +187,7 @@ struct Tally { unsigned node_visits, tri_tests, world_box, obj_trav, tlas_visits
                unsigned passes;                                                  // service passes (lane 0)
                unsigned long long clk_trav, clk_serv, clk_total, clk_fetch, clk_pop;
                unsigned long long sec[8];
-               unsigned hist[8]; };   // per-lane section profile of service_lane: ticks (0-3), calls (4-7)              // shader-clock ticks (lane 0)
+               unsigned hist[8], hist_shadow[8]; };   // per-lane section profile of service_lane: ticks (0-3), calls (4-7)              // shader-clock ticks (lane 0)
 
 #define RTX_STACK 100                // BLAS traversal stack entries per lane (BVH depth <= 64)
 #define RTX_TLAS_STACK 48
@@ -209,8 +209,8 @@ typedef __attribute__((address_space(1))) v4i glob_v4i;
 struct Wave { lds_double* rows; unsigned lane; };
 
 // Wave-cooperative gather of one 256-byte record per requesting lane into that lane's LDS row.
-// `mask` = ballot of the requesting lanes; `key` names the record: -1 = no request, otherwise bit 31 clear = BLAS node `key`, bit 31
-// set = the pair of triangle records starting at triangle `key & 0x7fffffff`.
+// `mask` = ballot of the requesting lanes; `key` names the record by its offset in 128-byte
+// units from `blas` (-1 = no request): a collapsed node, or a pair of triangle records.
 //
 // Sixteen lanes read one record as sixteen adjacent 16-byte pieces, so one load instruction
 // touches 4 records x 256 contiguous bytes instead of 64 scattered pieces.  The loads are
@@ -223,8 +223,7 @@ struct Wave { lds_double* rows; unsigned lane; };
 // here and to the slot index in row_read.  Must be executed by every lane of the wave.
 typedef __attribute__((address_space(3))) int lds_int;
 typedef __attribute__((address_space(3))) v4i lds_v4i;
-RTX_DEV void coop_fetch(const Wave& wv, unsigned long long mask, int key, const char* __restrict__ nodes,
-                        const char* __restrict__ tris) {
+RTX_DEV void coop_fetch(const Wave& wv, unsigned long long mask, int key, const char* __restrict__ blas) {
     const unsigned lane = wv.lane, quarter = lane >> 4, slot = lane & 15u;
     ((lds_int*)wv.rows)[(lane & 3u) * 16u + (lane >> 2)] = key;
     __builtin_amdgcn_wave_barrier();
@@ -247,8 +246,7 @@ RTX_DEV void coop_fetch(const Wave& wv, unsigned long long mask, int key, const 
         const int okey = okeys[g];
         const unsigned piece = slot ^ ((4u * g + quarter) & 15u);
         if (okey != -1) {
-            const unsigned idx = (unsigned)okey & 0x7FFFFFFFu;
-            const char* gp = (okey < 0 ? tris + (size_t)idx * sizeof(Tri) : nodes + (size_t)idx * sizeof(Node4)) + piece * 16u;
+            const char* gp = blas + ((size_t)(unsigned)okey << 7) + (piece << 4);
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gp,
                                              (__attribute__((address_space(3))) void*)(wv.rows + g * 4 * RTX_ROW_DOUBLES),
                                              16, 0, 0);
@@ -619,8 +617,8 @@ RTX_DEV bool job_next(const Scene& S, Lane& L, const RecOut& out, Tally& tl) {
 // here with the same arithmetic that accepted it (same inputs, same bits).
 RTX_DEV void job_finalize(const Scene& S, Lane& L, const RecOut& out) {
     if (L.btri < 0) return;
-    const int tri = L.btri;
-    const RTX_GLOBAL Tri* Tg = (const RTX_GLOBAL Tri*)S.tris + tri;
+    const int tri = L.btri - S.tri_key0;             // triangle index (the traversal works with record keys)
+    const RTX_GLOBAL Tri* Tg = (const RTX_GLOBAL Tri*)(S.blas + (size_t)(unsigned)L.btri * 128u);
     const RTX_GLOBAL Obj* ob = (const RTX_GLOBAL Obj*)S.objs + L.obj;
     double T[9];
 #pragma unroll
@@ -868,6 +866,7 @@ RTX_DEV void service_lane(const Launch* __restrict__ Lp, const int gen, double* 
         int b = 0;
         for (int a = L.age >> 4; a > 0 && b < 7; a >>= 1) b++;
         tl.hist[b]++;
+        if (L.is_shadow) tl.hist_shadow[b]++;
     }
 }
 
@@ -906,8 +905,7 @@ template <bool COUNT>
 RTX_DEV void traverse_steps(const Scene& S, const Wave& wv, Lane& L, glob_v4i* __restrict__ stk, const bool refillable,
                             Tally& tl) {
     const unsigned lane = wv.lane;
-    const char* const nodes = (const char*)S.nodes;
-    const char* const tris = (const char*)S.tris;
+    const char* const blas = S.blas;
     const bool cull = S.cull != 0;
     const double isect_eps = S.isect_eps;
     Slab sl;
@@ -940,13 +938,12 @@ RTX_DEV void traverse_steps(const Scene& S, const Wave& wv, Lane& L, glob_v4i* _
         double rec[32];
         if (__popcll(m_job) <= RTX_SPARSE_LANES) {
             if (in_job) {
-                const RTX_GLOBAL v2d* gp = (const RTX_GLOBAL v2d*)(at_leaf ? tris + (size_t)(unsigned)L.cur_ref * sizeof(Tri)
-                                                                           : nodes + (size_t)(unsigned)L.cur_ref * sizeof(Node4));
+                const RTX_GLOBAL v2d* gp = (const RTX_GLOBAL v2d*)(blas + ((size_t)(unsigned)L.cur_ref << 7));
 #pragma unroll
                 for (int p = 0; p < 16; p++) { const v2d v = gp[p]; rec[2 * p] = v.x; rec[2 * p + 1] = v.y; }
             }
         } else {
-            coop_fetch(wv, m_job, in_job ? (at_leaf ? (L.cur_ref | (int)0x80000000) : L.cur_ref) : -1, nodes, tris);
+            coop_fetch(wv, m_job, in_job ? L.cur_ref : -1, blas);
             if (in_job) row_read<0, 16>(wv, rec);
             __builtin_amdgcn_wave_barrier();
         }
@@ -1061,7 +1058,8 @@ k_trace(const Launch* __restrict__ Lp, GenCtrl* ctrl, const int gen, double* __r
     const Queue& qin = Lp->q[(gen + 1) & 1];
     __shared__ __attribute__((aligned(16))) double lds_rows[4][64 * RTX_ROW_DOUBLES];      // 64 KB per block
     Wave wv;
-    wv.rows = (lds_double*)&lds_rows[threadIdx.x >> 6][0];
+    // (wave-uniform by construction; saying so keeps the LDS-DMA destinations in scalar registers)
+    wv.rows = (lds_double*)(size_t)__builtin_amdgcn_readfirstlane((int)(size_t)(lds_double*)&lds_rows[threadIdx.x >> 6][0]);
     wv.lane = lane_id();
     const unsigned lane = wv.lane;
     GenCtrl* me = ctrl + gen;
@@ -1156,15 +1154,17 @@ k_trace(const Launch* __restrict__ Lp, GenCtrl* ctrl, const int gen, double* __r
 
     if (COUNT && counters) {
         const bool l0 = lane == 0;
-        unsigned long long v[38] = {tl.rays, tl.primary, tl.shadow, tl.secondary, tl.node_visits, tl.tri_tests,
+        unsigned long long v[46] = {tl.rays, tl.primary, tl.shadow, tl.secondary, tl.node_visits, tl.tri_tests,
                                     tl.world_box, tl.obj_trav, tl.tlas_visits, tl.inner_steps, tl.inner_lanes,
                                     tl.leaf_steps, tl.leaf_lanes, l0 ? tl.passes : 0u, l0 ? tl.clk_trav : 0ull,
                                     l0 ? tl.clk_serv : 0ull, l0 ? (unsigned long long)(clock64() - clk_begin) : 0ull,
                                     l0 ? 1ull : 0ull, l0 ? tl.clk_fetch : 0ull, l0 ? tl.clk_pop : 0ull, 0ull, 0ull,
                                     tl.sec[0], tl.sec[1], tl.sec[2], tl.sec[3], tl.sec[4], tl.sec[5], tl.sec[6], tl.sec[7],
-                                    tl.hist[0], tl.hist[1], tl.hist[2], tl.hist[3], tl.hist[4], tl.hist[5], tl.hist[6], tl.hist[7]};
+                                    tl.hist[0], tl.hist[1], tl.hist[2], tl.hist[3], tl.hist[4], tl.hist[5], tl.hist[6], tl.hist[7],
+                                    tl.hist_shadow[0], tl.hist_shadow[1], tl.hist_shadow[2], tl.hist_shadow[3], tl.hist_shadow[4],
+                                    tl.hist_shadow[5], tl.hist_shadow[6], tl.hist_shadow[7]};
 #pragma unroll
-        for (int k = 0; k < 38; k++) {
+        for (int k = 0; k < 46; k++) {
             unsigned long long x = v[k];
             for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off);
             if (lane == 0 && x) atomicAdd(((unsigned long long*)counters) + k, x);
