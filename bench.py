@@ -189,12 +189,21 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: there is no CPU path behind the C-ABI")
+    # Rehearsal on a one-GPU box (RTX_BENCH_REHEARSAL=1): every rank uses device 0 and the
+    # collectives run over gloo on host tensors; everything else is the multi-GPU code path.
+    rehearsal = os.environ.get("RTX_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
+    red_dev = "cpu" if rehearsal else "cuda"
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     def barrier():
         if dist is not None:
@@ -257,7 +266,7 @@ def main():
         pad = max(sizes)
         my_dev = torch.empty(pad, dtype=torch.uint8, device="cuda")
         if rank == 0 and world > 1:
-            gather_buf = [torch.empty(pad, dtype=torch.uint8, device="cuda") for _ in range(world)]
+            gather_buf = [torch.empty(pad, dtype=torch.uint8, device=red_dev) for _ in range(world)]
 
     def step():
         if args.mode == "frames":
@@ -265,7 +274,7 @@ def main():
             return st
         _, st = ds.render_tiles(cam, tw, th, rank, world, out_ptr=my_dev.data_ptr(), out_is_device=True)
         if world > 1:
-            dist.gather(my_dev, gather_buf, dst=0)
+            dist.gather(my_dev.cpu() if rehearsal else my_dev, gather_buf, dst=0)
         if rank == 0:
             parts = gather_buf if world > 1 else [my_dev]
             for r, t in enumerate(parts):
@@ -287,8 +296,8 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
 
-    el = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-    tot = torch.tensor([float(rays_rank), float(alg_bytes_rank)], dtype=torch.float64, device="cuda")
+    el = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
+    tot = torch.tensor([float(rays_rank), float(alg_bytes_rank)], dtype=torch.float64, device=red_dev)
     if dist is not None:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
