@@ -14,7 +14,9 @@ DEVSRC  := raytracer_amd/csrc
 # -ffp-contract=off everywhere: hit selection must round exactly like the reference
 # binary, which contains no fused multiply-adds.
 HOSTFLAGS := -O2 -std=c++17 -ffp-contract=off -fno-fast-math -fPIC -Wall -Wextra -Iinclude
-DEVFLAGS  := -O3 -std=c++17 --offload-arch=$(ARCH) -ffp-contract=off -fno-fast-math \
+# -fno-strict-aliasing: the kernels view the same LDS rows and global records through several
+# types (integer keys, 16-byte pieces, doubles); type-based alias analysis is not to reason about that.
+DEVFLAGS  := -O3 -std=c++17 --offload-arch=$(ARCH) -ffp-contract=off -fno-fast-math -fno-strict-aliasing \
              -munsafe-fp-atomics -fPIC -Wall -Iinclude
 
 .PHONY: all product checkers clean
