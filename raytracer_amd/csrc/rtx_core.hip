@@ -741,9 +741,12 @@ int rtx_render(rtx_scene* sc, const rtx_camera* cam, int32_t tw, int32_t th, int
                         "(at 2.4 GHz): %llu steps, %llu service passes\n", gen, c.rays, c.inner_steps + c.leaf_steps,
                         c.service_passes, (double)c.max_wave_ticks / 2400.0, c.max_wave_steps & 0xFFFFFFFFull, c.max_wave_steps >> 32);
                 const double nst = (double)std::max(1ull, c.inner_steps + c.leaf_steps);
-                fprintf(stderr, "[rtx]        ticks per wave-step: %.0f (fetch %.0f, pop %.0f); per service pass: %.0f\n",
+                fprintf(stderr, "[rtx]        ticks per wave-step: %.0f (fetch %.0f, pop %.0f); per service pass: %.0f; "
+                        "mean wave lifetime %.1f us (traversing %.1f, servicing %.1f)\n",
                         (double)c.clk_traverse / nst, (double)c.clk_fetch / nst, (double)c.clk_pop / nst,
-                        (double)c.clk_service / std::max(1ull, c.service_passes));
+                        (double)c.clk_service / std::max(1ull, c.service_passes),
+                        (double)c.clk_total / std::max(1ull, c.waves) / 2400.0, (double)c.clk_traverse / std::max(1ull, c.waves) / 2400.0,
+                        (double)c.clk_service / std::max(1ull, c.waves) / 2400.0);
                 fprintf(stderr, "[rtx]        rays by steps (<16 <32 <64 <128 <256 <512 <1024 more): %llu %llu %llu %llu %llu %llu %llu %llu\n",
                         c.ray_steps_hist[0], c.ray_steps_hist[1], c.ray_steps_hist[2], c.ray_steps_hist[3], c.ray_steps_hist[4],
                         c.ray_steps_hist[5], c.ray_steps_hist[6], c.ray_steps_hist[7]);
