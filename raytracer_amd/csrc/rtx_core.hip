@@ -73,7 +73,8 @@ struct rtx_scene {
     uint32_t queue_capacity = 0;    // rays per queue, grows on overflow and is then kept
     DevBuf materials, lights, xforms, planes, spheres, ftris, meshes, insts, objs, blas, tri_vn,
         tlas, tlas_order;
-    DevBuf accum, rgb, aov, ctrl, counters, queue[2], hitbuf, launch, stacks;
+    DevBuf accum, rgb, aov, ctrl, counters, queue[2], hitbuf, launch, stacks, inst_bits;
+    size_t inst_bits_cleared = 0;   // bytes of inst_bits known to be all zero
     ~rtx_scene() {
         for (hipEvent_t e : gen_events) (void)hipEventDestroy(e);
         if (ev0) (void)hipEventDestroy(ev0);
@@ -612,6 +613,17 @@ int rtx_render(rtx_scene* sc, const rtx_camera* cam, int32_t tw, int32_t th, int
     // One grid of resident blocks: RTX_TRACE_WAVES waves per SIMD = that many 256-thread blocks per CU.
     const unsigned persistent_blocks = (unsigned)dev_cus * (unsigned)RTX_TRACE_WAVES;
     HIP_TRY(sc->stacks.ensure((size_t)persistent_blocks * 256u * RTX_STACK * 16u));
+    // one bit per instance per lane; every ray leaves its lane's bitmap clear, so it is zeroed once
+    const uint32_t inst_words = ((uint32_t)std::max(sc->dev.n_insts, 1) + 31u) / 32u;
+    {
+        const size_t bytes = (size_t)persistent_blocks * 256u * inst_words * sizeof(uint32_t);
+        if (bytes > ((size_t)8 << 30)) return fail(RTX_ELIMIT, "too many instances for the per-lane instance bitmaps");
+        if (bytes > sc->inst_bits.bytes || sc->inst_bits_cleared < bytes) {
+            HIP_TRY(sc->inst_bits.ensure(bytes));
+            HIP_TRY(hipMemsetAsync(sc->inst_bits.p, 0, sc->inst_bits.bytes, sc->stream));
+            sc->inst_bits_cleared = sc->inst_bits.bytes;
+        }
+    }
 
     if (sc->queue_capacity == 0) {
         int64_t want = std::max<int64_t>(n_local_px * (int64_t)(sc->dev.n_lights + 2), 1 << 16);
@@ -637,6 +649,7 @@ int rtx_render(rtx_scene* sc, const rtx_camera* cam, int32_t tw, int32_t th, int
         launch.q[1] = make_queue(sc->queue[1].p, sc->queue_capacity);
         launch.hb = make_hitbuf(sc->hitbuf.p, hit_cap);
         launch.stacks = sc->stacks.p;
+        launch.inst_bits = (unsigned*)sc->inst_bits.p; launch.inst_words = inst_words; launch.pad_launch = 0;
         HIP_TRY(sc->launch.ensure(sizeof(Launch)));
         // pageable source: the copy is staged before the call returns, so `launch` may go out of scope
         HIP_TRY(hipMemcpyAsync(sc->launch.p, &launch, sizeof launch, hipMemcpyHostToDevice, sc->stream));

@@ -186,6 +186,10 @@ struct Launch {
     // entries contiguous (a push or pop touches one cache line per lane), indexed by
     // (global wave number * 64 + lane).
     void* stacks;
+    // Instance bitmaps of the trace kernel: inst_words 32-bit words per lane (one bit per instance),
+    // all clear between rays; indexed like the stacks.
+    unsigned* inst_bits;
+    uint32_t inst_words, pad_launch;
 };
 
 struct Counters {

@@ -392,14 +392,16 @@ RTX_DEV void free_tri_hit(const Scene& S, V3 ro, V3 rd, int index, double& t_min
     }
 }
 
-#define RTX_CAND 8
-
-// Collect, for one ray, the RTX_CAND smallest instance indices > last whose world box the ray
-// meets within the bound (TLAS walk; per-lane, no cross-lane work).
+// Mark, in the lane's instance bitmap, every instance whose TLAS leaf the ray meets within the
+// bound (one TLAS walk per ray; per-lane, no cross-lane work).  The bitmap is consumed in
+// ascending bit order, which is the instance order the reference's loop imposes
+// (utils.cpp:756-790).  wlo/whi return the range of bitmap words touched.  Marks and reads go
+// through device-scope atomics: they execute at L2, so the lane always sees its own updates.
 template <bool COUNT>
-RTX_DEV void tlas_collect(const Scene& S, const Slab& sl, double t_min, int last, int (&buf)[RTX_CAND], Tally& tl) {
+RTX_DEV void tlas_mark(const Scene& S, const Slab& sl, double t_min, unsigned* bits, int& wlo, int& whi, Tally& tl) {
+    wlo = INT_MAX; whi = -1;
     double enter;
-    if (!(S.tl_max_idx > last && box_enter(S.tl_min, S.tl_max, sl, enter) && (t_min >= enter))) return;
+    if (!(box_enter(S.tl_min, S.tl_max, sl, enter) && (t_min >= enter))) return;
     int stk_ref[RTX_TLAS_STACK], stk_cnt[RTX_TLAS_STACK];
     int sp = 1;
     stk_ref[0] = S.tl_ref; stk_cnt[0] = S.tl_count;
@@ -409,25 +411,18 @@ RTX_DEV void tlas_collect(const Scene& S, const Slab& sl, double t_min, int last
         if (cnt > 0) {
             for (int k = 0; k < cnt; k++) {
                 const int idx = S.tlas_order[ref + k];
-                if (idx > last && idx < buf[RTX_CAND - 1]) {
-                    int x = idx;                 // sorted insert, largest falls off
-#pragma unroll
-                    for (int q = 0; q < RTX_CAND; q++) {
-                        const int lo = min(buf[q], x), hi = max(buf[q], x);
-                        buf[q] = lo; x = hi;
-                    }
-                }
+                const int w = idx >> 5;
+                atomicOr(bits + w, 1u << (idx & 31));
+                wlo = min(wlo, w); whi = max(whi, w);
             }
         } else {
             const TlasNode& n = S.tlas[ref];
             if (COUNT) tl.tlas_visits++;
             double e;
-            if (n.lmax_idx > last && n.lmin_idx < buf[RTX_CAND - 1] && box_enter(n.lmin, n.lmax, sl, e) &&
-                (t_min >= e) && sp < RTX_TLAS_STACK) {
+            if (box_enter(n.lmin, n.lmax, sl, e) && (t_min >= e) && sp < RTX_TLAS_STACK) {
                 stk_ref[sp] = n.lref; stk_cnt[sp] = n.lcount; sp++;
             }
-            if (n.rmax_idx > last && n.rmin_idx < buf[RTX_CAND - 1] && box_enter(n.rmin, n.rmax, sl, e) &&
-                (t_min >= e) && sp < RTX_TLAS_STACK) {
+            if (box_enter(n.rmin, n.rmax, sl, e) && (t_min >= e) && sp < RTX_TLAS_STACK) {
                 stk_ref[sp] = n.rref; stk_cnt[sp] = n.rcount; sp++;
             }
         }
@@ -467,9 +462,11 @@ struct Lane {
     double t_min, dist;     // current bound; Intersection::distance of the record
     unsigned slot;          // queue slot (work item for generation 0) = hit-record slot
     int is_shadow, hit;
-    // object iterator: it <= n_meshes: meshes (job = object it-1); it > n_meshes: instances (job = object n_meshes + last)
-    int it, last, more;
-    int buf[RTX_CAND];
+    // object iterator: it <= n_meshes: meshes (job = object it-1); it > n_meshes: instances, taken in
+    // ascending index from the lane's instance bitmap: word `word` is being consumed, `bits` are
+    // its remaining candidates, `whi` is the last word that holds any
+    int it, word, whi;
+    unsigned bits;
     // current traversal job
     int obj;
     double orig_t_min;
@@ -526,9 +523,7 @@ RTX_DEV void ray_begin(const Scene& S, Lane& L, const RecOut& out, Tally& tl) {
         }
         L.hit = hit ? 1 : 0;
     }
-    L.it = 0; L.last = -1; L.more = 0; L.age = 0;
-#pragma unroll
-    for (int k = 0; k < RTX_CAND; k++) L.buf[k] = INT_MAX;
+    L.it = 0; L.word = 0; L.whi = -1; L.bits = 0u; L.age = 0;
     L.state = LS_NEED_JOB;
 }
 
@@ -536,7 +531,7 @@ RTX_DEV void ray_begin(const Scene& S, Lane& L, const RecOut& out, Tally& tl) {
 // up: rayHitsMesh's prologue, utils.cpp:418-494 + the root test of bvh.cpp:132) or the
 // object sequence is exhausted (returns false).
 template <bool COUNT>
-RTX_DEV bool job_next(const Scene& S, Lane& L, const RecOut& out, Tally& tl) {
+RTX_DEV bool job_next(const Scene& S, Lane& L, const RecOut& out, unsigned* inst_bits, Tally& tl) {
     const RTX_GLOBAL Obj* const objs = (const RTX_GLOBAL Obj*)S.objs;
     while (true) {
         int oi;
@@ -560,24 +555,26 @@ RTX_DEV bool job_next(const Scene& S, Lane& L, const RecOut& out, Tally& tl) {
                     }
                     L.hit = hit ? 1 : 0;
                 }
-                L.more = S.n_insts > 0 ? 1 : 0;
+                // Instances (utils.cpp:756-790).  One TLAS walk marks the candidates --
+                // instances whose world box the ray can meet within the current bound; a box
+                // missed now stays missed because the bound never grows.  They are then replayed
+                // in ascending index through the reference's own per-instance logic (world-box
+                // test against the then-current bound included).
+                if (S.n_insts > 0) {
+                    const Slab ws = make_slab(L.o, L.d);
+                    int wlo;
+                    tlas_mark<COUNT>(S, ws, L.t_min, inst_bits, wlo, L.whi, tl);
+                    L.word = wlo == INT_MAX ? 0 : wlo - 1;
+                    L.bits = 0u;
+                }
             }
-            // Instances (utils.cpp:756-790).  The TLAS only selects candidates -- instances
-            // whose world box the ray meets within the current bound; a box missed now stays
-            // missed because the bound never grows.  Candidates are replayed in ascending
-            // index, RTX_CAND at a time, through the reference's own per-instance logic.
-            if (L.buf[0] == INT_MAX) {
-                if (!L.more) return false;
-                const Slab ws = make_slab(L.o, L.d);
-                tlas_collect<COUNT>(S, ws, L.t_min, L.last, L.buf, tl);
-                L.more = L.buf[RTX_CAND - 1] != INT_MAX ? 1 : 0;
-                if (L.buf[0] == INT_MAX) return false;
+            while (L.bits == 0u) {
+                if (L.word >= L.whi) return false;
+                L.word++;
+                L.bits = atomicExch(inst_bits + L.word, 0u);       // take the word's candidates, leave it clear
             }
-            const int idx = L.buf[0];
-#pragma unroll
-            for (int q = 0; q + 1 < RTX_CAND; q++) L.buf[q] = L.buf[q + 1];
-            L.buf[RTX_CAND - 1] = INT_MAX;
-            L.last = idx;
+            const int idx = L.word * 32 + (__ffs((int)L.bits) - 1);
+            L.bits &= L.bits - 1u;
             oi = S.n_meshes + idx;
         }
         const RTX_GLOBAL Obj* ob = objs + oi;
@@ -830,7 +827,8 @@ RTX_DEV void service_lane(const Launch* __restrict__ Lp, const int gen, double* 
         job_finalize(S, L, out); L.state = LS_NEED_JOB;
         if (COUNT) { const long long c = clock64(); tl.sec[1] += (unsigned long long)(c - c0); tl.sec[5]++; c0 = c; }
     }
-    const bool more = job_next<COUNT>(S, L, out, tl);
+    unsigned* inst_bits = Lp->inst_bits + (size_t)((blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 64u + lane_id()) * Lp->inst_words;
+    const bool more = job_next<COUNT>(S, L, out, inst_bits, tl);
     if (COUNT) { const long long c = clock64(); tl.sec[2] += (unsigned long long)(c - c0); tl.sec[6]++; c0 = c; }
     if (more) { L.state = LS_IN_JOB; return; }
     // ---- ray complete ------------------------------------------------------------------------
@@ -1085,7 +1083,7 @@ k_trace(const Launch* __restrict__ Lp, GenCtrl* ctrl, const int gen, double* __r
     Lane L;
     L.state = LS_EMPTY; L.cur_cnt = 0; L.cur_ref = 0; L.sp = 0; L.slot = 0; L.is_shadow = 0; L.btri = -1; L.obj = 0;
     L.top = (v4i)(0); L.t_min = 0.0; L.ro = mk(0, 0, 0); L.rd = mk(0, 0, 1); L.ix = L.iy = L.iz = 0.0; L.par = 0;
-    L.o = mk(0, 0, 0); L.d = mk(0, 0, 1);
+    L.o = mk(0, 0, 0); L.d = mk(0, 0, 1); L.it = 0; L.word = 0; L.whi = -1; L.bits = 0u; L.age = 0;
 
     while (true) {
         const int state = L.state;
