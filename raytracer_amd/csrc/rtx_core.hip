@@ -71,8 +71,7 @@ struct rtx_scene {
     bool counters_on = false;
     int64_t queue_limit = (int64_t)32 << 30;
     uint32_t queue_capacity = 0;    // rays per queue, grows on overflow and is then kept
-    DevBuf materials, lights, xforms, planes, spheres, ftris, meshes, insts, objs, blas, tri_vn,
-        tlas, tlas_order;
+    DevBuf materials, lights, xforms, planes, spheres, ftris, meshes, insts, objs, blas, tri_vn;
     DevBuf accum, rgb, aov, ctrl, counters, queue[2], hitbuf, launch, stacks, inst_bits;
     size_t inst_bits_cleared = 0;   // bytes of inst_bits known to be all zero
     ~rtx_scene() {
@@ -219,44 +218,58 @@ int flatten_mesh(const rtx_scene_desc& d, const rtx_mesh& m, Flat& F) {
 // ---- TLAS ---------------------------------------------------------------------------------
 struct TlasItem { HBox box; int idx; double c[3]; };
 
+// TLAS over the instances' world boxes, written as Node4 records of the same array the BLAS
+// records live in: median split on the widest centroid axis, two binary levels per record.  A
+// slot with cnt == -2 is an instance (ref = instance index).  The order of the slots carries no
+// meaning: the walk only marks candidates.
 struct TlasBuild {
     std::vector<TlasItem>& items;
-    std::vector<TlasNode>& nodes;
-    std::vector<int32_t>& order;
-    struct Sub { int32_t ref, cnt, min_idx, max_idx; HBox box; };
+    std::vector<Node4>& nodes;
 
-    Sub build(int lo, int hi) {
-        Sub s;
-        s.min_idx = INT_MAX; s.max_idx = -1;
-        for (int i = lo; i < hi; i++) {
-            s.box.merge(items[(size_t)i].box);
-            s.min_idx = std::min(s.min_idx, items[(size_t)i].idx);
-            s.max_idx = std::max(s.max_idx, items[(size_t)i].idx);
-        }
-        if (hi - lo <= 2) {
-            std::sort(items.begin() + lo, items.begin() + hi, [](const TlasItem& a, const TlasItem& b) { return a.idx < b.idx; });
-            s.ref = (int32_t)order.size(); s.cnt = hi - lo;
-            for (int i = lo; i < hi; i++) order.push_back(items[(size_t)i].idx);
-            return s;
-        }
+    HBox range_box(int lo, int hi) const {
+        HBox b;
+        for (int i = lo; i < hi; i++) b.merge(items[(size_t)i].box);
+        return b;
+    }
+    int split(int lo, int hi) {
         double cmn[3] = {1e300, 1e300, 1e300}, cmx[3] = {-1e300, -1e300, -1e300};
         for (int i = lo; i < hi; i++)
             for (int k = 0; k < 3; k++) { cmn[k] = std::min(cmn[k], items[(size_t)i].c[k]); cmx[k] = std::max(cmx[k], items[(size_t)i].c[k]); }
         int axis = 0;
         for (int k = 1; k < 3; k++) if (cmx[k] - cmn[k] > cmx[axis] - cmn[axis]) axis = k;
-        int mid = lo + (hi - lo) / 2;
+        const int mid = lo + (hi - lo) / 2;
         std::nth_element(items.begin() + lo, items.begin() + mid, items.begin() + hi,
                          [axis](const TlasItem& a, const TlasItem& b) { return a.c[axis] < b.c[axis]; });
-        int32_t self = (int32_t)nodes.size();
+        return mid;
+    }
+    void slot(Node4& o, int s, const HBox& box, int32_t ref, int32_t cnt) {
+        memcpy(o.box[s], box.mn, 24); memcpy(o.box[s] + 3, box.mx, 24);
+        o.ref[s] = ref; o.cnt[s] = cnt;
+    }
+    void fill(Node4& o, int s, int lo, int hi) {       // one slot for items [lo, hi)
+        if (hi - lo == 1) slot(o, s, items[(size_t)lo].box, items[(size_t)lo].idx, -2);
+        else { const int32_t child = make(lo, hi); slot(o, s, range_box(lo, hi), child, 0); }
+    }
+    int32_t make(int lo, int hi) {                      // record for items [lo, hi), at least one
+        const int32_t id = (int32_t)nodes.size();
         nodes.emplace_back();
-        Sub l = build(lo, mid), r = build(mid, hi);
-        TlasNode& n = nodes[(size_t)self];
-        memcpy(n.lmin, l.box.mn, 24); memcpy(n.lmax, l.box.mx, 24);
-        memcpy(n.rmin, r.box.mn, 24); memcpy(n.rmax, r.box.mx, 24);
-        n.lref = l.ref; n.lcount = l.cnt; n.rref = r.ref; n.rcount = r.cnt;
-        n.lmin_idx = l.min_idx; n.lmax_idx = l.max_idx; n.rmin_idx = r.min_idx; n.rmax_idx = r.max_idx;
-        s.ref = self; s.cnt = 0;
-        return s;
+        Node4 o;
+        memset(&o, 0, sizeof o);
+        for (int s = 0; s < 4; s++) o.cnt[s] = -1;
+        if (hi - lo == 1) fill(o, 0, lo, hi);
+        else {
+            const int mid = split(lo, hi);
+            const int part[3] = {lo, mid, hi};
+            for (int p = 0; p < 2; p++) {
+                const int a = part[p], b = part[p + 1];
+                if (b - a == 1) { fill(o, 2 * p, a, b); continue; }
+                const int m2 = split(a, b);
+                fill(o, 2 * p, a, m2);
+                fill(o, 2 * p + 1, m2, b);
+            }
+        }
+        nodes[(size_t)id] = o;
+        return id;
     }
 };
 
@@ -349,14 +362,6 @@ int build_scene(rtx_scene& sc, const rtx_scene_desc& d) {
     }
     if (F.tris.size() > (size_t)INT_MAX / 2) return fail(RTX_ELIMIT, "too many triangles");
     { Tri pad_tri; memset(&pad_tri, 0, sizeof pad_tri); F.tris.push_back(pad_tri); }   // leaf steps fetch triangles in pairs
-    // record indices -> keys (offsets in 128-byte units into the joint node + triangle allocation)
-    if (2 * F.nodes.size() + F.tris.size() > (size_t)INT_MAX) return fail(RTX_ELIMIT, "BLAS larger than 256 GB");
-    const int32_t tri_key0 = (int32_t)(2 * F.nodes.size());
-    auto to_key = [&](int32_t& ref, int32_t cnt) { if (cnt > 0) ref += tri_key0; else if (cnt == 0) ref *= 2; };
-    for (Node4& n : F.nodes) for (int k = 0; k < 4; k++) to_key(n.ref[k], n.cnt[k]);
-    for (Mesh& m : F.meshes) if (m.n_faces > 0) to_key(m.root_ref, m.root_count);
-    S.tri_key0 = tri_key0;
-
     // instances: effective transform (utils.cpp:418,446,476) and TLAS over their world boxes
     std::vector<Inst> insts((size_t)d.n_instances);
     std::vector<TlasItem> items;
@@ -383,15 +388,23 @@ int build_scene(rtx_scene& sc, const rtx_scene_desc& d) {
         for (int k = 0; k < 3; k++) it.c[k] = 0.5 * it.box.mn[k] + 0.5 * it.box.mx[k];
         items.push_back(it);
     }
-    std::vector<TlasNode> tlas;
-    std::vector<int32_t> order;
+    int32_t tlas_root = -1;
     if (!items.empty()) {
-        TlasBuild tb{items, tlas, order};
-        TlasBuild::Sub root = tb.build(0, (int)items.size());
-        memcpy(S.tl_min, root.box.mn, 24); memcpy(S.tl_max, root.box.mx, 24);
-        S.tl_ref = root.ref; S.tl_count = root.cnt; S.tl_min_idx = root.min_idx; S.tl_max_idx = root.max_idx;
+        TlasBuild tb{items, F.nodes};
+        const HBox all = tb.range_box(0, (int)items.size());
+        memcpy(S.tl_min, all.mn, 24); memcpy(S.tl_max, all.mx, 24);
+        tlas_root = tb.make(0, (int)items.size());
         S.n_insts = d.n_instances;
     }
+    // record indices -> keys (offsets in 128-byte units into the joint node + triangle allocation)
+    if (2 * F.nodes.size() + F.tris.size() > (size_t)INT_MAX) return fail(RTX_ELIMIT, "BLAS larger than 256 GB");
+    const int32_t tri_key0 = (int32_t)(2 * F.nodes.size());
+    auto to_key = [&](int32_t& ref, int32_t cnt) { if (cnt > 0) ref += tri_key0; else if (cnt == 0) ref *= 2; };
+    for (Node4& n : F.nodes) for (int k = 0; k < 4; k++) to_key(n.ref[k], n.cnt[k]);
+    for (Mesh& m : F.meshes) if (m.n_faces > 0) to_key(m.root_ref, m.root_count);
+    S.tri_key0 = tri_key0;
+
+    S.tl_key = tlas_root >= 0 ? 2 * tlas_root : 0;
 
     // per-object records: meshes first, then instances
     std::vector<Obj> objs((size_t)d.n_meshes + (size_t)d.n_instances);
@@ -437,8 +450,6 @@ int build_scene(rtx_scene& sc, const rtx_scene_desc& d) {
         // no smooth mesh: keep has_vn = 0 everywhere, nothing to upload
         S.tri_vn = nullptr;
     }
-    HIP_TRY(sc.tlas.upload(tlas));        S.tlas = (const TlasNode*)sc.tlas.p;
-    HIP_TRY(sc.tlas_order.upload(order)); S.tlas_order = (const int32_t*)sc.tlas_order.p;
     return RTX_OK;
 }
 

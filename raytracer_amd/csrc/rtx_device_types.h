@@ -6,11 +6,12 @@
 //            at a time: one 256-byte record holds the boxes of up to four grandchildren of a
 //            binary node; leaves are ranges of a triangle array stored in leaf order (the
 //            order of MeshBVH::faceIndices), each triangle pre-gathered as (a, b-a, c-a).
-//   TLAS  -- a spatial BVH over the world boxes of the mesh instances, built here (the
-//            reference scans instances linearly, utils.cpp:756-790).  It only *selects
-//            candidates*; candidates are then processed in ascending instance index with
-//            the reference's own per-instance logic, because the result of the reference's
-//            loop depends on that order (utils.cpp:483-489,510 and 567-570).
+//   TLAS  -- a spatial BVH over the world boxes of the mesh instances, built here in the same
+//            four-wide record format (the reference scans instances linearly,
+//            utils.cpp:756-790).  It only *selects candidates* (marks them in a per-lane
+//            bitmap); candidates are then processed in ascending instance index with the
+//            reference's own per-instance logic, because the result of the reference's loop
+//            depends on that order (utils.cpp:483-489,510 and 567-570).
 #pragma once
 #include <stdint.h>
 
@@ -21,7 +22,8 @@ namespace rtxdev {
 // Slots 0,1 belong to the left child of the binary node the record stands for, slots 2,3 to its
 // right child: an inner child contributes its own two children, a leaf child sits in the first
 // slot of its pair and leaves the second empty.  cnt: 0 = inner (ref = Node4 index),
-// > 0 = leaf owning the cnt triangle records from ref on, -1 = empty slot.  ref is a record key
+// > 0 = leaf owning the cnt triangle records from ref on, -1 = empty slot, -2 (TLAS records
+// only) = mesh instance `ref`.  ref is a record key
 // (offset in 128-byte units, see Scene::blas).
 // axis0 / axisL / axisR are BVHNode::splitAxis of the binary node, its left and its right child:
 // the near side of a split is the left one iff dir[axis] >= 0 (bvh.cpp:139-147).
@@ -48,14 +50,6 @@ struct Mesh {
     int32_t material, smooth, xform, n_faces;
     int32_t has_vn, pad;
 };
-
-// TLAS inner node: child boxes + the index range of the instances below each child.
-struct TlasNode {
-    double lmin[3], lmax[3], rmin[3], rmax[3];
-    int32_t lref, lcount, rref, rcount;      // count > 0: leaf over tlas_order[ref .. ref+count)
-    int32_t lmin_idx, lmax_idx, rmin_idx, rmax_idx;
-};
-static_assert(sizeof(TlasNode) == 128, "TlasNode must be 128 bytes");
 
 struct Inst {
     int32_t base_mesh, material;
@@ -122,11 +116,10 @@ struct Scene {
     const char* blas;
     int32_t tri_key0, pad_blas;
     const double* tri_vn;     // RTX_VN_STRIDE per triangle (vertex normals of its corners) or null
-    const TlasNode* tlas;
-    const int32_t* tlas_order;
-    // TLAS root (may itself be a leaf)
+    // TLAS: Node4 records among the BLAS records (a slot with cnt == -2 is instance `ref`);
+    // box of everything and key of the root record
     double tl_min[3], tl_max[3];
-    int32_t tl_ref, tl_count, tl_min_idx, tl_max_idx;
+    int32_t tl_key, pad_tl;
 };
 
 // Per-frame camera basis, precomputed on the host with the arithmetic of utils.cpp:135-146.

@@ -392,43 +392,6 @@ RTX_DEV void free_tri_hit(const Scene& S, V3 ro, V3 rd, int index, double& t_min
     }
 }
 
-// Mark, in the lane's instance bitmap, every instance whose TLAS leaf the ray meets within the
-// bound (one TLAS walk per ray; per-lane, no cross-lane work).  The bitmap is consumed in
-// ascending bit order, which is the instance order the reference's loop imposes
-// (utils.cpp:756-790).  wlo/whi return the range of bitmap words touched.  Marks and reads go
-// through device-scope atomics: they execute at L2, so the lane always sees its own updates.
-template <bool COUNT>
-RTX_DEV void tlas_mark(const Scene& S, const Slab& sl, double t_min, unsigned* bits, int& wlo, int& whi, Tally& tl) {
-    wlo = INT_MAX; whi = -1;
-    double enter;
-    if (!(box_enter(S.tl_min, S.tl_max, sl, enter) && (t_min >= enter))) return;
-    int stk_ref[RTX_TLAS_STACK], stk_cnt[RTX_TLAS_STACK];
-    int sp = 1;
-    stk_ref[0] = S.tl_ref; stk_cnt[0] = S.tl_count;
-    while (sp > 0) {
-        --sp;
-        const int ref = stk_ref[sp], cnt = stk_cnt[sp];
-        if (cnt > 0) {
-            for (int k = 0; k < cnt; k++) {
-                const int idx = S.tlas_order[ref + k];
-                const int w = idx >> 5;
-                atomicOr(bits + w, 1u << (idx & 31));
-                wlo = min(wlo, w); whi = max(whi, w);
-            }
-        } else {
-            const TlasNode& n = S.tlas[ref];
-            if (COUNT) tl.tlas_visits++;
-            double e;
-            if (box_enter(n.lmin, n.lmax, sl, e) && (t_min >= e) && sp < RTX_TLAS_STACK) {
-                stk_ref[sp] = n.lref; stk_cnt[sp] = n.lcount; sp++;
-            }
-            if (box_enter(n.rmin, n.rmax, sl, e) && (t_min >= e) && sp < RTX_TLAS_STACK) {
-                stk_ref[sp] = n.rref; stk_cnt[sp] = n.rcount; sp++;
-            }
-        }
-    }
-}
-
 // ---------------------------------------------------------------------------------------
 // Per-lane ray state of the trace kernel.
 //
@@ -555,17 +518,25 @@ RTX_DEV bool job_next(const Scene& S, Lane& L, const RecOut& out, unsigned* inst
                     }
                     L.hit = hit ? 1 : 0;
                 }
-                // Instances (utils.cpp:756-790).  One TLAS walk marks the candidates --
-                // instances whose world box the ray can meet within the current bound; a box
-                // missed now stays missed because the bound never grows.  They are then replayed
-                // in ascending index through the reference's own per-instance logic (world-box
-                // test against the then-current bound included).
+                // Instances (utils.cpp:756-790).  A walk of the TLAS -- a traversal job like a
+                // mesh's, run by the cooperative loop with the world-space ray -- marks the
+                // candidates in the lane's bitmap: instances whose world box the ray can meet
+                // within the current bound (a box missed now stays missed because the bound
+                // never grows).  They are then replayed in ascending index through the
+                // reference's own per-instance logic (world-box test against the then-current
+                // bound included).
+                L.word = INT_MAX; L.whi = -1; L.bits = 0u;
                 if (S.n_insts > 0) {
                     const Slab ws = make_slab(L.o, L.d);
-                    int wlo;
-                    tlas_mark<COUNT>(S, ws, L.t_min, inst_bits, wlo, L.whi, tl);
-                    L.word = wlo == INT_MAX ? 0 : wlo - 1;
-                    L.bits = 0u;
+                    double tl_min[3] = {S.tl_min[0], S.tl_min[1], S.tl_min[2]}, tl_max[3] = {S.tl_max[0], S.tl_max[1], S.tl_max[2]};
+                    double enter;
+                    if (box_enter(tl_min, tl_max, ws, enter) && (L.t_min >= enter)) {
+                        L.obj = -1;                                  // marks the job as the TLAS walk
+                        L.orig_t_min = L.t_min;
+                        L.ro = L.o; L.rd = L.d; L.ix = ws.ix; L.iy = ws.iy; L.iz = ws.iz; L.par = ws.par;
+                        L.cur_ref = S.tl_key; L.cur_cnt = 0; L.sp = 0; L.btri = -1;
+                        return true;
+                    }
                 }
             }
             while (L.bits == 0u) {
@@ -810,7 +781,7 @@ RTX_DEV V3 primary_direction(const Frame& F, int px, int py) {
 // (L.slot / L.o / L.d / L.is_shadow set).
 template <bool COUNT>
 RTX_DEV void service_lane(const Launch* __restrict__ Lp, const int gen, double* __restrict__ accum,
-                          rtx_hit_id* __restrict__ aov, Lane& L, const bool fresh, Tally& tl) {
+                          rtx_hit_id* __restrict__ aov, Lane& L, unsigned* inst_bits, const bool fresh, Tally& tl) {
     const Scene& S = Lp->S;
     const Frame& F = Lp->F;
     const Queue& qin = Lp->q[(gen + 1) & 1];
@@ -824,10 +795,17 @@ RTX_DEV void service_lane(const Launch* __restrict__ Lp, const int gen, double* 
         if (COUNT) { const long long c = clock64(); tl.sec[0] += (unsigned long long)(c - c0); tl.sec[4]++; c0 = c; }
     }
     if (L.state == LS_JOB_DONE) {
-        job_finalize(S, L, out); L.state = LS_NEED_JOB;
+        if (L.obj == -1) {
+            // end of the TLAS walk: L.word .. L.whi is the range of bitmap words it marked;
+            // consumption starts in front of the first of them
+            L.word = L.word == INT_MAX ? L.whi : L.word - 1;
+            L.obj = -2;
+        } else {
+            job_finalize(S, L, out);
+        }
+        L.state = LS_NEED_JOB;
         if (COUNT) { const long long c = clock64(); tl.sec[1] += (unsigned long long)(c - c0); tl.sec[5]++; c0 = c; }
     }
-    unsigned* inst_bits = Lp->inst_bits + (size_t)((blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 64u + lane_id()) * Lp->inst_words;
     const bool more = job_next<COUNT>(S, L, out, inst_bits, tl);
     if (COUNT) { const long long c = clock64(); tl.sec[2] += (unsigned long long)(c - c0); tl.sec[6]++; c0 = c; }
     if (more) { L.state = LS_IN_JOB; return; }
@@ -900,8 +878,8 @@ RTX_DEV void cand_swap(Cand& a, Cand& b, bool doit) {
 }
 
 template <bool COUNT>
-RTX_DEV void traverse_steps(const Scene& S, const Wave& wv, Lane& L, glob_v4i* __restrict__ stk, const bool refillable,
-                            Tally& tl) {
+RTX_DEV void traverse_steps(const Scene& S, const Wave& wv, Lane& L, glob_v4i* __restrict__ stk, unsigned* inst_bits,
+                            const bool refillable, Tally& tl) {
     const unsigned lane = wv.lane;
     const char* const blas = S.blas;
     const bool cull = S.cull != 0;
@@ -952,7 +930,7 @@ RTX_DEV void traverse_steps(const Scene& S, const Wave& wv, Lane& L, glob_v4i* _
             if (COUNT) L.age++;
             if (!at_leaf) {
                 // ---- collapsed inner node: up to four grandchildren of a binary node ------------
-                if (COUNT) tl.node_visits++;
+                if (COUNT) { if (L.obj == -1) tl.tlas_visits++; else tl.node_visits++; }
                 const double* nd = rec;
                 Cand c[4];
 #pragma unroll
@@ -964,7 +942,14 @@ RTX_DEV void traverse_steps(const Scene& S, const Wave& wv, Lane& L, glob_v4i* _
                     if (any_par) hit = box_enter(nd + 6 * k, nd + 6 * k + 3, sl, e);
                     else hit = box_enter_nopar(nd + 6 * k, nd + 6 * k + 3, sl, e);
                     c[k].e = e;
-                    c[k].ok = hit & (L.t_min >= e) & (c[k].cnt >= 0);
+                    const bool pass = hit & (L.t_min >= e);
+                    c[k].ok = pass & (c[k].cnt >= 0);
+                    if (pass && c[k].cnt == -2) {
+                        // TLAS walk: the slot is a mesh instance whose world box the ray can meet
+                        const int w = c[k].ref >> 5;
+                        atomicOr(inst_bits + w, 1u << (c[k].ref & 31));
+                        L.word = min(L.word, w); L.whi = max(L.whi, w);
+                    }
                 }
                 // Visit order of the reference: at each binary split the near child first, near =
                 // left iff dir[splitAxis] >= 0 (bvh.cpp:139-147).  Slots 0,1 hang under the left
@@ -1080,6 +1065,7 @@ k_trace(const Launch* __restrict__ Lp, GenCtrl* ctrl, const int gen, double* __r
 
     glob_v4i* const stk = (glob_v4i*)Lp->stacks +
                           ((size_t)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 64u + lane) * RTX_STACK;
+    unsigned* const inst_bits = Lp->inst_bits + ((size_t)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 64u + lane) * Lp->inst_words;
     Lane L;
     L.state = LS_EMPTY; L.cur_cnt = 0; L.cur_ref = 0; L.sp = 0; L.slot = 0; L.is_shadow = 0; L.btri = -1; L.obj = 0;
     L.top = (v4i)(0); L.t_min = 0.0; L.ro = mk(0, 0, 0); L.rd = mk(0, 0, 1); L.ix = L.iy = L.iz = 0.0; L.par = 0;
@@ -1138,7 +1124,7 @@ k_trace(const Launch* __restrict__ Lp, GenCtrl* ctrl, const int gen, double* __r
                     }
                 }
                 if (fresh || L.state == LS_JOB_DONE || L.state == LS_NEED_JOB)
-                    service_lane<COUNT>(Lp, gen, accum, aov, L, fresh, tl);
+                    service_lane<COUNT>(Lp, gen, accum, aov, L, inst_bits, fresh, tl);
                 if (drained || __ballot(L.state == LS_EMPTY) == 0ull) break;
             }
             if (COUNT) { tl.clk_serv += (unsigned long long)(clock64() - c0); tl.passes++; }
@@ -1146,7 +1132,7 @@ k_trace(const Launch* __restrict__ Lp, GenCtrl* ctrl, const int gen, double* __r
         }
         if (m_trav == 0ull) break;
         const long long c1 = COUNT ? clock64() : 0;
-        traverse_steps<COUNT>(S, wv, L, stk, !drained, tl);
+        traverse_steps<COUNT>(S, wv, L, stk, inst_bits, !drained, tl);
         if (COUNT) tl.clk_trav += (unsigned long long)(clock64() - c1);
     }
 
