@@ -625,7 +625,7 @@ int rtx_render(rtx_scene* sc, const rtx_camera* cam, int32_t tw, int32_t th, int
     const unsigned persistent_blocks = (unsigned)dev_cus * (unsigned)RTX_TRACE_WAVES;
     HIP_TRY(sc->stacks.ensure((size_t)persistent_blocks * 256u * RTX_STACK * 16u));
     // one bit per instance per lane; every ray leaves its lane's bitmap clear, so it is zeroed once
-    const uint32_t inst_words = ((uint32_t)std::max(sc->dev.n_insts, 1) + 31u) / 32u;
+    const uint32_t inst_words = rtx_bitmap_words(sc->dev.n_insts) + rtx_summary_words(sc->dev.n_insts);
     {
         const size_t bytes = (size_t)persistent_blocks * 256u * inst_words * sizeof(uint32_t);
         if (bytes > ((size_t)8 << 30)) return fail(RTX_ELIMIT, "too many instances for the per-lane instance bitmaps");

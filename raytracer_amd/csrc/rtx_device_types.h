@@ -17,6 +17,16 @@
 
 namespace rtxdev {
 
+// words of the per-lane instance bitmap and of its summary level, for n instances
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+inline unsigned rtx_bitmap_words(int n) { return ((unsigned)(n > 0 ? n : 1) + 31u) / 32u; }
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+inline unsigned rtx_summary_words(int n) { return (rtx_bitmap_words(n) + 31u) / 32u; }
+
 // Inner BLAS node: two levels of the reference's binary BVH collapsed into one 256-byte
 // record (sixteen 16-byte pieces), so that a traversal step descends two binary levels.
 // Slots 0,1 belong to the left child of the binary node the record stands for, slots 2,3 to its
@@ -179,8 +189,9 @@ struct Launch {
     // entries contiguous (a push or pop touches one cache line per lane), indexed by
     // (global wave number * 64 + lane).
     void* stacks;
-    // Instance bitmaps of the trace kernel: inst_words 32-bit words per lane (one bit per instance),
-    // all clear between rays; indexed like the stacks.
+    // Instance bitmaps of the trace kernel, two levels: per lane rtx_summary_words(n) summary words
+    // (bit w = bitmap word w holds a candidate) followed by ceil(n/32) bitmap words (one bit per
+    // instance); inst_words is their sum.  All clear between rays; indexed like the stacks.
     unsigned* inst_bits;
     uint32_t inst_words, pad_launch;
 };

@@ -426,10 +426,12 @@ struct Lane {
     unsigned slot;          // queue slot (work item for generation 0) = hit-record slot
     int is_shadow, hit;
     // object iterator: it <= n_meshes: meshes (job = object it-1); it > n_meshes: instances, taken in
-    // ascending index from the lane's instance bitmap: word `word` is being consumed, `bits` are
-    // its remaining candidates, `whi` is the last word that holds any
-    int it, word, whi;
-    unsigned bits;
+    // ascending index from the lane's two-level instance bitmap: bitmap word `word` is being
+    // consumed (`bits` = its remaining candidates); which words hold any is recorded in summary
+    // words, of which `sword` is being consumed (`sbits`) and `whi` is the last that has any.
+    // While the TLAS walk runs, word/whi are the lowest/highest bitmap word it has marked.
+    int it, word, whi, sword;
+    unsigned bits, sbits;
     // current traversal job
     int obj;
     double orig_t_min;
@@ -486,7 +488,7 @@ RTX_DEV void ray_begin(const Scene& S, Lane& L, const RecOut& out, Tally& tl) {
         }
         L.hit = hit ? 1 : 0;
     }
-    L.it = 0; L.word = 0; L.whi = -1; L.bits = 0u; L.age = 0;
+    L.it = 0; L.word = 0; L.whi = -1; L.bits = 0u; L.sword = 0; L.sbits = 0u; L.age = 0;
     L.state = LS_NEED_JOB;
 }
 
@@ -496,6 +498,8 @@ RTX_DEV void ray_begin(const Scene& S, Lane& L, const RecOut& out, Tally& tl) {
 template <bool COUNT>
 RTX_DEV bool job_next(const Scene& S, Lane& L, const RecOut& out, unsigned* inst_bits, Tally& tl) {
     const RTX_GLOBAL Obj* const objs = (const RTX_GLOBAL Obj*)S.objs;
+    const unsigned n_summary = rtx_summary_words(S.n_insts);
+    const Slab ws = make_slab(L.o, L.d);         // world-space slab constants, once per call
     while (true) {
         int oi;
         if (L.it < S.n_meshes) {                                     // utils.cpp:736-739
@@ -525,9 +529,8 @@ RTX_DEV bool job_next(const Scene& S, Lane& L, const RecOut& out, unsigned* inst
                 // never grows).  They are then replayed in ascending index through the
                 // reference's own per-instance logic (world-box test against the then-current
                 // bound included).
-                L.word = INT_MAX; L.whi = -1; L.bits = 0u;
+                L.word = INT_MAX; L.whi = -1; L.bits = 0u; L.sbits = 0u; L.sword = -1;
                 if (S.n_insts > 0) {
-                    const Slab ws = make_slab(L.o, L.d);
                     double tl_min[3] = {S.tl_min[0], S.tl_min[1], S.tl_min[2]}, tl_max[3] = {S.tl_max[0], S.tl_max[1], S.tl_max[2]};
                     double enter;
                     if (box_enter(tl_min, tl_max, ws, enter) && (L.t_min >= enter)) {
@@ -540,41 +543,54 @@ RTX_DEV bool job_next(const Scene& S, Lane& L, const RecOut& out, unsigned* inst
                 }
             }
             while (L.bits == 0u) {
-                if (L.word >= L.whi) return false;
-                L.word++;
-                L.bits = atomicExch(inst_bits + L.word, 0u);       // take the word's candidates, leave it clear
+                while (L.sbits == 0u) {
+                    if (L.sword >= L.whi) return false;
+                    L.sword++;
+                    L.sbits = atomicExch(inst_bits + L.sword, 0u);           // summary words come first in the lane's area
+                }
+                L.word = L.sword * 32 + (__ffs((int)L.sbits) - 1);
+                L.sbits &= L.sbits - 1u;
+                L.bits = atomicExch(inst_bits + n_summary + L.word, 0u);     // take the word's candidates, leave it clear
             }
             const int idx = L.word * 32 + (__ffs((int)L.bits) - 1);
             L.bits &= L.bits - 1u;
             oi = S.n_meshes + idx;
         }
+        // second 128 bytes of the object record in one batch: world box, root box, root, flags
         const RTX_GLOBAL Obj* ob = objs + oi;
-        const int flags = ob->flags;
+        double ob2[16];
+        {
+            const RTX_GLOBAL v2d* p2 = (const RTX_GLOBAL v2d*)ob->bmin;
+#pragma unroll
+            for (int k = 0; k < 7; k++) { const v2d v = p2[k]; ob2[2 * k] = v.x; ob2[2 * k + 1] = v.y; }
+        }
+        const int root_ref = __double2loint(ob2[12]), root_count = __double2hiint(ob2[12]);
+        const int flags = __double2loint(ob2[13]);
         if (flags & OBJ_SKIP) continue;
         V3 ro = L.o, rd = L.d;
         if (flags & OBJ_XF) {
             if (flags & OBJ_BOUNDS) {                                // utils.cpp:446-466, 760-766
                 if (COUNT) tl.world_box++;
-                const Slab ws = make_slab(L.o, L.d);
-                double bmin[3] = {ob->bmin[0], ob->bmin[1], ob->bmin[2]}, bmax[3] = {ob->bmax[0], ob->bmax[1], ob->bmax[2]};
                 double enter;
-                if (!box_enter(bmin, bmax, ws, enter) || !(L.t_min >= enter)) continue;
+                if (!box_enter(ob2 + 0, ob2 + 3, ws, enter) || !(L.t_min >= enter)) continue;
             }
             if (COUNT) tl.obj_trav++;
             double inv[16];
+            {
+                const RTX_GLOBAL v2d* p1 = (const RTX_GLOBAL v2d*)ob->inv;
 #pragma unroll
-            for (int k = 0; k < 16; k++) inv[k] = ob->inv[k];
+                for (int k = 0; k < 8; k++) { const v2d v = p1[k]; inv[2 * k] = v.x; inv[2 * k + 1] = v.y; }
+            }
             ro = xf_point(inv, L.o);                                 // utils.cpp:481-489
             rd = normalize_f32(xf_dir(inv, L.d));
         }
         const Slab sl = make_slab(ro, rd);
-        double rmin[3] = {ob->rmin[0], ob->rmin[1], ob->rmin[2]}, rmax[3] = {ob->rmax[0], ob->rmax[1], ob->rmax[2]};
         double enter;
-        if (!box_enter(rmin, rmax, sl, enter) || !(L.t_min >= enter)) continue;
+        if (!box_enter(ob2 + 6, ob2 + 9, sl, enter) || !(L.t_min >= enter)) continue;
         L.obj = oi;
         L.orig_t_min = L.t_min;
         L.ro = ro; L.rd = rd; L.ix = sl.ix; L.iy = sl.iy; L.iz = sl.iz; L.par = sl.par;
-        L.cur_ref = ob->root_ref; L.cur_cnt = ob->root_count; L.sp = 0; L.btri = -1;
+        L.cur_ref = root_ref; L.cur_cnt = root_count; L.sp = 0; L.btri = -1;
         return true;
     }
 }
@@ -797,8 +813,10 @@ RTX_DEV void service_lane(const Launch* __restrict__ Lp, const int gen, double* 
     if (L.state == LS_JOB_DONE) {
         if (L.obj == -1) {
             // end of the TLAS walk: L.word .. L.whi is the range of bitmap words it marked;
-            // consumption starts in front of the first of them
-            L.word = L.word == INT_MAX ? L.whi : L.word - 1;
+            // consumption starts in front of the first summary word that covers them
+            L.sword = L.word == INT_MAX ? -1 : (L.word >> 5) - 1;
+            L.whi = L.whi < 0 ? -1 : (L.whi >> 5);
+            L.bits = 0u; L.sbits = 0u;
             L.obj = -2;
         } else {
             job_finalize(S, L, out);
@@ -881,6 +899,7 @@ template <bool COUNT>
 RTX_DEV void traverse_steps(const Scene& S, const Wave& wv, Lane& L, glob_v4i* __restrict__ stk, unsigned* inst_bits,
                             const bool refillable, Tally& tl) {
     const unsigned lane = wv.lane;
+    const unsigned n_summary = rtx_summary_words(S.n_insts);
     const char* const blas = S.blas;
     const bool cull = S.cull != 0;
     const double isect_eps = S.isect_eps;
@@ -947,7 +966,8 @@ RTX_DEV void traverse_steps(const Scene& S, const Wave& wv, Lane& L, glob_v4i* _
                     if (pass && c[k].cnt == -2) {
                         // TLAS walk: the slot is a mesh instance whose world box the ray can meet
                         const int w = c[k].ref >> 5;
-                        atomicOr(inst_bits + w, 1u << (c[k].ref & 31));
+                        atomicOr(inst_bits + n_summary + w, 1u << (c[k].ref & 31));
+                        atomicOr(inst_bits + (w >> 5), 1u << (w & 31));
                         L.word = min(L.word, w); L.whi = max(L.whi, w);
                     }
                 }
@@ -1069,7 +1089,7 @@ k_trace(const Launch* __restrict__ Lp, GenCtrl* ctrl, const int gen, double* __r
     Lane L;
     L.state = LS_EMPTY; L.cur_cnt = 0; L.cur_ref = 0; L.sp = 0; L.slot = 0; L.is_shadow = 0; L.btri = -1; L.obj = 0;
     L.top = (v4i)(0); L.t_min = 0.0; L.ro = mk(0, 0, 0); L.rd = mk(0, 0, 1); L.ix = L.iy = L.iz = 0.0; L.par = 0;
-    L.o = mk(0, 0, 0); L.d = mk(0, 0, 1); L.it = 0; L.word = 0; L.whi = -1; L.bits = 0u; L.age = 0;
+    L.o = mk(0, 0, 0); L.d = mk(0, 0, 1); L.it = 0; L.word = 0; L.whi = -1; L.bits = 0u; L.sword = 0; L.sbits = 0u; L.age = 0;
 
     while (true) {
         const int state = L.state;
