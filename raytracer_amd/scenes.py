@@ -522,6 +522,8 @@ UNIT_SCENES = {
     "marching_small": lambda d: scene_marching(d, faces=2000, res=(96, 54), name="marching_small"),
     "david_small": lambda d: scene_david_frame(d, 17, faces=1500, res=(64, 64), name="david_small"),
     "grass_small": lambda d: scene_grass(d, n_instances=300, res=(96, 54), name="grass_small"),
+    # more than 1024 instances: the device's instance bitmap needs more than one summary word
+    "grass_many": lambda d: scene_grass(d, n_instances=1500, res=(64, 36), name="grass_many", seed=4242),
 }
 
 
