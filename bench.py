@@ -412,6 +412,9 @@ def main():
                          "algorithmic_source": alg_source, "counters_agree": counters_agree,
                          "reference_work_counts": ref_counts,
                          "device_record_visits": int(cst["node_visits"]), "tri_tests": int(cst["tri_tests"]),
+                         "device_world_box_tests": int(cst["world_box_tests"]),
+                         "device_object_space_traversals": int(cst["object_space_traversals"]),
+                         "device_tlas_node_visits": int(cst["tlas_node_visits"]),
                          "lanes_at_nodes_per_wave_step": cst["wave_inner_lanes"] / max(cst["wave_inner_steps"], 1),
                          "lanes_at_leaves_per_wave_step": cst["wave_leaf_lanes"] / max(cst["wave_leaf_steps"], 1),
                          "wave_steps_with_node_lanes": int(cst["wave_inner_steps"]),

@@ -231,12 +231,57 @@ struct TlasBuild {
         for (int i = lo; i < hi; i++) b.merge(items[(size_t)i].box);
         return b;
     }
-    int split(int lo, int hi) {
+    static double half_area(const HBox& b) {
+        const double dx = b.mx[0] - b.mn[0], dy = b.mx[1] - b.mn[1], dz = b.mx[2] - b.mn[2];
+        return dx * dy + dy * dz + dz * dx;
+    }
+    // Partition items [lo, hi) in two: binned surface-area heuristic over the three axes, median
+    // of the widest centroid axis when no binned split separates the items or `sah` is off.  The
+    // TLAS only selects candidates, so its shape is free (unlike a BLAS, which is the reference's
+    // own tree).  The walk pushes up to three entries per record level: the heuristic is used
+    // for the first kSahLevels levels and the median below, which bounds the depth at
+    // kSahLevels + 16 levels (96 entries of the RTX_STACK-entry stack).
+    static constexpr int kSahLevels = 16;
+    int split(int lo, int hi, bool sah) {
         double cmn[3] = {1e300, 1e300, 1e300}, cmx[3] = {-1e300, -1e300, -1e300};
         for (int i = lo; i < hi; i++)
             for (int k = 0; k < 3; k++) { cmn[k] = std::min(cmn[k], items[(size_t)i].c[k]); cmx[k] = std::max(cmx[k], items[(size_t)i].c[k]); }
         int axis = 0;
         for (int k = 1; k < 3; k++) if (cmx[k] - cmn[k] > cmx[axis] - cmn[axis]) axis = k;
+        constexpr int kBins = 16;
+        int best_axis = -1, best_bin = -1;
+        double best_cost = 1e300;
+        if (sah && hi - lo > 4) {
+            for (int k = 0; k < 3; k++) {
+                const double w = cmx[k] - cmn[k];
+                if (!(w > 0.0) || !(w < 1e299)) continue;
+                HBox bb[kBins]; int bn[kBins] = {};
+                const double scale = kBins / w;
+                for (int i = lo; i < hi; i++) {
+                    const int b = std::min(kBins - 1, std::max(0, (int)((items[(size_t)i].c[k] - cmn[k]) * scale)));
+                    bb[b].merge(items[(size_t)i].box); bn[b]++;
+                }
+                double right_area[kBins]; int right_n[kBins];
+                HBox acc; int n = 0;
+                for (int b = kBins - 1; b > 0; b--) { acc.merge(bb[b]); n += bn[b]; right_area[b] = n ? half_area(acc) : 0.0; right_n[b] = n; }
+                HBox left; int ln = 0;
+                for (int b = 0; b + 1 < kBins; b++) {
+                    left.merge(bb[b]); ln += bn[b];
+                    if (ln == 0 || right_n[b + 1] == 0) continue;
+                    const double cost = half_area(left) * ln + right_area[b + 1] * right_n[b + 1];
+                    if (cost < best_cost) { best_cost = cost; best_axis = k; best_bin = b; }
+                }
+            }
+        }
+        if (best_axis >= 0) {
+            const int k = best_axis;
+            const double scale = kBins / (cmx[k] - cmn[k]), c0 = cmn[k];
+            const int bin = best_bin;
+            auto mid = std::partition(items.begin() + lo, items.begin() + hi, [=](const TlasItem& a) {
+                return std::min(kBins - 1, std::max(0, (int)((a.c[k] - c0) * scale))) <= bin; });
+            const int m = (int)(mid - items.begin());
+            if (m > lo && m < hi) return m;
+        }
         const int mid = lo + (hi - lo) / 2;
         std::nth_element(items.begin() + lo, items.begin() + mid, items.begin() + hi,
                          [axis](const TlasItem& a, const TlasItem& b) { return a.c[axis] < b.c[axis]; });
@@ -246,26 +291,27 @@ struct TlasBuild {
         memcpy(o.box[s], box.mn, 24); memcpy(o.box[s] + 3, box.mx, 24);
         o.ref[s] = ref; o.cnt[s] = cnt;
     }
-    void fill(Node4& o, int s, int lo, int hi) {       // one slot for items [lo, hi)
+    void fill(Node4& o, int s, int lo, int hi, int level) {       // one slot for items [lo, hi)
         if (hi - lo == 1) slot(o, s, items[(size_t)lo].box, items[(size_t)lo].idx, -2);
-        else { const int32_t child = make(lo, hi); slot(o, s, range_box(lo, hi), child, 0); }
+        else { const int32_t child = make(lo, hi, level + 1); slot(o, s, range_box(lo, hi), child, 0); }
     }
-    int32_t make(int lo, int hi) {                      // record for items [lo, hi), at least one
+    int32_t make(int lo, int hi, int level = 0) {       // record for items [lo, hi), at least one
         const int32_t id = (int32_t)nodes.size();
         nodes.emplace_back();
         Node4 o;
         memset(&o, 0, sizeof o);
         for (int s = 0; s < 4; s++) o.cnt[s] = -1;
-        if (hi - lo == 1) fill(o, 0, lo, hi);
+        const bool sah = level < kSahLevels;
+        if (hi - lo == 1) fill(o, 0, lo, hi, level);
         else {
-            const int mid = split(lo, hi);
+            const int mid = split(lo, hi, sah);
             const int part[3] = {lo, mid, hi};
             for (int p = 0; p < 2; p++) {
                 const int a = part[p], b = part[p + 1];
-                if (b - a == 1) { fill(o, 2 * p, a, b); continue; }
-                const int m2 = split(a, b);
-                fill(o, 2 * p, a, m2);
-                fill(o, 2 * p + 1, m2, b);
+                if (b - a == 1) { fill(o, 2 * p, a, b, level); continue; }
+                const int m2 = split(a, b, sah);
+                fill(o, 2 * p, a, m2, level);
+                fill(o, 2 * p + 1, m2, b, level);
             }
         }
         nodes[(size_t)id] = o;
