@@ -706,7 +706,11 @@ int rtx_render(rtx_scene* sc, const rtx_camera* cam, int32_t tw, int32_t th, int
         launch.q[1] = make_queue(sc->queue[1].p, sc->queue_capacity);
         launch.hb = make_hitbuf(sc->hitbuf.p, hit_cap);
         launch.stacks = sc->stacks.p;
-        launch.inst_bits = (unsigned*)sc->inst_bits.p; launch.inst_words = inst_words; launch.pad_launch = 0;
+        launch.inst_bits = (unsigned*)sc->inst_bits.p; launch.inst_words = inst_words;
+        // A service pass lasts as long as its slowest lane.  Replaying instance candidates makes
+        // that long (a chain of dependent loads per candidate), so scenes with many instances
+        // gather more lanes per pass.
+        launch.service_threshold = sc->dev.n_insts >= 256 ? RTX_SERVICE_THRESHOLD_INSTANCED : RTX_SERVICE_THRESHOLD;
         HIP_TRY(sc->launch.ensure(sizeof(Launch)));
         // pageable source: the copy is staged before the call returns, so `launch` may go out of scope
         HIP_TRY(hipMemcpyAsync(sc->launch.p, &launch, sizeof launch, hipMemcpyHostToDevice, sc->stream));

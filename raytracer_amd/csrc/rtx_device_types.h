@@ -193,7 +193,9 @@ struct Launch {
     // (bit w = bitmap word w holds a candidate) followed by ceil(n/32) bitmap words (one bit per
     // instance); inst_words is their sum.  All clear between rays; indexed like the stacks.
     unsigned* inst_bits;
-    uint32_t inst_words, pad_launch;
+    uint32_t inst_words;
+    // Lanes waiting for service that make a wave of the trace kernel leave its traversal loop.
+    uint32_t service_threshold;
 };
 
 struct Counters {

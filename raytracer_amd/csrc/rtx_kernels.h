@@ -413,7 +413,8 @@ RTX_DEV void free_tri_hit(const Scene& S, V3 ro, V3 rd, int index, double& t_min
 // ---------------------------------------------------------------------------------------
 enum { LS_EMPTY = 0, LS_NEED_JOB = 1, LS_JOB_DONE = 2, LS_IN_JOB = 3 };
 
-#define RTX_SERVICE_THRESHOLD 24     // lanes waiting for service that trigger a service pass
+#define RTX_SERVICE_THRESHOLD 24     // lanes waiting for service that trigger a service pass ...
+#define RTX_SERVICE_THRESHOLD_INSTANCED 36   // ... and in scenes where a pass replays many instance candidates
 #define RTX_SPARSE_LANES 2           // at most this many traversing lanes: load records directly
 #define RTX_CHUNK 256                // rays a wave claims per atomic
 #ifndef RTX_TRACE_WAVES
@@ -897,7 +898,7 @@ RTX_DEV void cand_swap(Cand& a, Cand& b, bool doit) {
 
 template <bool COUNT>
 RTX_DEV void traverse_steps(const Scene& S, const Wave& wv, Lane& L, glob_v4i* __restrict__ stk, unsigned* inst_bits,
-                            const bool refillable, Tally& tl) {
+                            const int service_threshold, const bool refillable, Tally& tl) {
     const unsigned lane = wv.lane;
     const unsigned n_summary = rtx_summary_words(S.n_insts);
     const char* const blas = S.blas;
@@ -913,7 +914,7 @@ RTX_DEV void traverse_steps(const Scene& S, const Wave& wv, Lane& L, glob_v4i* _
         if (m_job == 0ull) break;
         const unsigned long long m_wait = __ballot(L.state == LS_NEED_JOB || L.state == LS_JOB_DONE ||
                                                    (refillable && L.state == LS_EMPTY));
-        if (__popcll(m_wait) >= RTX_SERVICE_THRESHOLD) break;
+        if (__popcll(m_wait) >= service_threshold) break;
         if (COUNT) {
             const int nl = __popcll(__ballot(at_leaf)), nj = __popcll(m_job);
             if (lane == 0) {
@@ -1086,6 +1087,7 @@ k_trace(const Launch* __restrict__ Lp, GenCtrl* ctrl, const int gen, double* __r
     glob_v4i* const stk = (glob_v4i*)Lp->stacks +
                           ((size_t)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 64u + lane) * RTX_STACK;
     unsigned* const inst_bits = Lp->inst_bits + ((size_t)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 64u + lane) * Lp->inst_words;
+    const int service_threshold = (int)Lp->service_threshold;
     Lane L;
     L.state = LS_EMPTY; L.cur_cnt = 0; L.cur_ref = 0; L.sp = 0; L.slot = 0; L.is_shadow = 0; L.btri = -1; L.obj = 0;
     L.top = (v4i)(0); L.t_min = 0.0; L.ro = mk(0, 0, 0); L.rd = mk(0, 0, 1); L.ix = L.iy = L.iz = 0.0; L.par = 0;
@@ -1098,7 +1100,7 @@ k_trace(const Launch* __restrict__ Lp, GenCtrl* ctrl, const int gen, double* __r
         const unsigned long long m_trav = __ballot(state == LS_IN_JOB);
         const int n_service = __popcll(m_need) + (drained ? 0 : __popcll(m_empty));
 
-        if (n_service > 0 && (m_trav == 0ull || n_service >= RTX_SERVICE_THRESHOLD)) {
+        if (n_service > 0 && (m_trav == 0ull || n_service >= service_threshold)) {
             // ---- service pass ---------------------------------------------------------------
             const long long c0 = COUNT ? clock64() : 0;
             for (int rep = 0; rep < 4; rep++) {
@@ -1152,7 +1154,7 @@ k_trace(const Launch* __restrict__ Lp, GenCtrl* ctrl, const int gen, double* __r
         }
         if (m_trav == 0ull) break;
         const long long c1 = COUNT ? clock64() : 0;
-        traverse_steps<COUNT>(S, wv, L, stk, inst_bits, !drained, tl);
+        traverse_steps<COUNT>(S, wv, L, stk, inst_bits, service_threshold, !drained, tl);
         if (COUNT) tl.clk_trav += (unsigned long long)(clock64() - c1);
     }
 
