@@ -32,7 +32,7 @@ $(LIBDIR)/librtx_amd.so: $(DEVSRC)/rtx_core.hip $(wildcard $(DEVSRC)/*.h) includ
 	$(HIPCC) $(DEVFLAGS) -shared -o $@ $(DEVSRC)/rtx_core.hip
 
 $(LIBDIR)/raytracer_amd: $(HOSTSRC)/main.cpp $(LIBDIR)/librtx_host.so $(LIBDIR)/librtx_amd.so
-	$(CXX) $(HOSTFLAGS) -o $@ $(HOSTSRC)/main.cpp -L$(LIBDIR) -lrtx_host -lrtx_amd \
+	$(CXX) $(HOSTFLAGS) -pthread -o $@ $(HOSTSRC)/main.cpp -L$(LIBDIR) -lrtx_host -lrtx_amd \
 	    -Wl,-rpath,'$$ORIGIN' -Wl,-rpath-link,/opt/rocm/lib
 
 checkers:

@@ -28,7 +28,18 @@ typedef struct rtx_host_scene rtx_host_scene;
  * use_bvh the -b flag (raytracer.cpp:190-198, default 1). */
 int rtx_host_load(const char* json_path, int use_bvh, int enable_cull, rtx_host_scene** out);
 
-/* The description; valid until rtx_host_free. */
+/* Next frame of an animation.  The reference starts one process per frame file and redoes
+ * parsing, BVH build and precompute each time (runner.py:105-141); frames of an animation
+ * usually differ only in cameras and point lights.  When `json_path` describes the geometry
+ * `prev` holds -- same document apart from "Cameras" and "Lights"/"PointLight", same
+ * directory, PLY files unchanged on disk -- only cameras and lights are re-read into `prev`
+ * (transformations applied as in scene.cpp:971-987), `*out = prev`, `*reused = 1`, and the
+ * description's geometry pointers stay as they were: a device scene made from it needs
+ * rtx_scene_update_lights only.  Otherwise the file is loaded from scratch with prev's flags,
+ * `prev` is freed, `*out` is the new scene and `*reused = 0`.  On failure `prev` stays valid. */
+int rtx_host_load_next(const char* json_path, rtx_host_scene* prev, rtx_host_scene** out, int* reused);
+
+/* The description; valid until rtx_host_free (light array: until the next rtx_host_load_next). */
 const rtx_scene_desc* rtx_host_desc(const rtx_host_scene* scene);
 
 int rtx_host_camera_count(const rtx_host_scene* scene);

@@ -58,6 +58,22 @@ class HostScene:
         self._h = h
         self.path = json_path
 
+    def load_next(self, json_path: str) -> bool:
+        """Next frame of an animation (rtx_host_load_next).  Returns True when the geometry was
+        kept and only cameras and lights were re-read: a DeviceScene made from this scene then
+        needs ``update_lights(hs.lights())`` only.  False: everything was reloaded and the
+        description is a new one."""
+        h, reused = C.c_void_p(), C.c_int(0)
+        if self._lib.rtx_host_load_next(os.fsencode(json_path), self._h, C.byref(h), C.byref(reused)) != 0:
+            raise RtxError(self._lib.rtx_host_last_error().decode())
+        self._h = h
+        self.path = json_path
+        return bool(reused.value)
+
+    def lights(self):
+        d = self.desc.contents
+        return [d.lights[i] for i in range(d.n_lights)]
+
     @property
     def desc(self):
         return self._lib.rtx_host_desc(self._h)

@@ -114,7 +114,7 @@ AMD_SYMBOLS = ["rtx_scene_create", "rtx_scene_update_lights", "rtx_render",
                "rtx_render_output_bytes", "rtx_unpack_tiles", "rtx_scene_set_counters",
                "rtx_scene_set_queue_limit", "rtx_scene_destroy", "rtx_last_error",
                "rtx_device_count"]
-HOST_SYMBOLS = ["rtx_host_load", "rtx_host_desc", "rtx_host_camera_count", "rtx_host_camera",
+HOST_SYMBOLS = ["rtx_host_load", "rtx_host_load_next", "rtx_host_desc", "rtx_host_camera_count", "rtx_host_camera",
                 "rtx_host_timings", "rtx_host_dump", "rtx_host_free", "rtx_host_write_ppm",
                 "rtx_host_write_png", "rtx_host_last_error"]
 
@@ -123,6 +123,8 @@ def load_host_lib():
     lib = C.CDLL(os.path.join(LIB_DIR, "librtx_host.so"))
     lib.rtx_host_load.argtypes = [C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
     lib.rtx_host_load.restype = C.c_int
+    lib.rtx_host_load_next.argtypes = [C.c_char_p, C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int)]
+    lib.rtx_host_load_next.restype = C.c_int
     lib.rtx_host_desc.argtypes = [C.c_void_p]
     lib.rtx_host_desc.restype = C.POINTER(SceneDesc)
     lib.rtx_host_camera_count.argtypes = [C.c_void_p]

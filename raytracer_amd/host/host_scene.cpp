@@ -18,6 +18,8 @@
 #include <string>
 #include <vector>
 
+#include <sys/stat.h>
+
 #include "rtx_host.h"
 #include "json_min.hpp"
 #include "ply_reader.hpp"
@@ -240,6 +242,13 @@ struct rtx_host_scene {
     std::string base_dir;
     double parse_ms = 0, preprocess_ms = 0;
     bool last_mesh_smooth = false;   // see parse_mesh
+    // What the geometry was built from, kept so that the next frame of an animation can tell
+    // whether it shares it: the scene document minus its cameras and point lights, the load
+    // flags, and size + modification time of every PLY file read.
+    Json geometry_doc;
+    bool use_bvh = true, cull = false;
+    struct FileStamp { std::string path; long long size; long long mtime_ns; };
+    std::vector<FileStamp> files;
 
     // utils.cpp:1308-1351: result = I; for i = n-1 .. 0: result = result * T_i
     Mat4 object_matrix(const std::vector<TRef>& refs) const {
@@ -386,6 +395,81 @@ void parse_common(const rtx_host_scene& s, const Json& j, HostObject& o) {   // 
     if (j.has("Transformations")) o.tf = parse_trefs(j["Transformations"].str());
 }
 
+rtx_host_scene::FileStamp file_stamp(const std::string& path) {
+    struct stat st;
+    if (stat(path.c_str(), &st) != 0) return {path, -1, -1};
+    return {path, (long long)st.st_size, (long long)st.st_mtim.tv_sec * 1000000000LL + (long long)st.st_mtim.tv_nsec};
+}
+
+// Cameras and point lights of a scene document, with their transformations applied
+// (scene.cpp:343-415, 971-987).  Replaces what the scene held.
+void parse_view(rtx_host_scene& s, const Json& sc) {
+    auto put = [](double* dst, V3 v) { dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; };
+    s.cameras.clear(); s.lights.clear(); s.light_tf.clear();
+    if (sc.has("Cameras"))
+        for_each_item(sc["Cameras"]["Camera"], [&](const Json& j) {
+            unsigned id; HostCamera c = parse_camera(j, id);
+            if (id != 0) s.cameras.push_back(c);
+        });
+    if (sc.has("Lights")) {
+        const Json& L = sc["Lights"];
+        if (L.has("PointLight"))
+            for_each_item(L["PointLight"], [&](const Json& j) {
+                unsigned id = (unsigned)parse_long(j["_id"].str());
+                rtx_light l{};
+                put(l.position, parse_v3(j["Position"].str()));
+                put(l.intensity, parse_v3(j["Intensity"].str()));
+                if (id != 0) {
+                    s.lights.push_back(l);
+                    s.light_tf.push_back(j.has("Transformations") ? parse_trefs(j["Transformations"].str()) : std::vector<TRef>());
+                }
+            });
+    }
+}
+void transform_view(rtx_host_scene& s) {
+    auto put = [](double* dst, V3 v) { dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; };
+    for (HostCamera& hc : s.cameras)                                     // scene.cpp:971-979
+        if (!hc.tf.empty()) {
+            Mat4 M = s.object_matrix(hc.tf);
+            rtx_camera& c = hc.cam;
+            V3 p = xf_point(M, {c.position[0], c.position[1], c.position[2]});
+            V3 g = normalize(xf_dir(M, {c.gaze[0], c.gaze[1], c.gaze[2]}));
+            V3 u = normalize(xf_dir(M, {c.up[0], c.up[1], c.up[2]}));
+            put(c.position, p); put(c.gaze, g); put(c.up, u);
+        }
+    for (size_t i = 0; i < s.lights.size(); i++)                         // scene.cpp:981-987
+        if (!s.light_tf[i].empty()) {
+            Mat4 M = s.object_matrix(s.light_tf[i]);
+            rtx_light& l = s.lights[i];
+            put(l.position, xf_point(M, {l.position[0], l.position[1], l.position[2]}));
+        }
+}
+
+// The scene document without the parts a frame of an animation may change freely.
+Json geometry_part(const Json& sc) {
+    Json g = sc;
+    for (size_t i = 0; i < g.members.size();) {
+        if (g.members[i].first == "Cameras") g.members.erase(g.members.begin() + (long)i);
+        else i++;
+    }
+    for (auto& m : g.members) {
+        if (m.first != "Lights" || !m.second.is_object()) continue;
+        auto& lm = m.second.members;
+        for (size_t i = 0; i < lm.size();) {
+            if (lm[i].first == "PointLight") lm.erase(lm.begin() + (long)i);
+            else i++;
+        }
+    }
+    return g;
+}
+bool same_json(const Json& a, const Json& b) {
+    if (a.type != b.type || a.text != b.text || a.items.size() != b.items.size() || a.members.size() != b.members.size()) return false;
+    for (size_t i = 0; i < a.items.size(); i++) if (!same_json(a.items[i], b.items[i])) return false;
+    for (size_t i = 0; i < a.members.size(); i++)
+        if (a.members[i].first != b.members[i].first || !same_json(a.members[i].second, b.members[i].second)) return false;
+    return true;
+}
+
 void parse_faces(rtx_host_scene& s, const Json& j, std::vector<int32_t>& faces) {   // scene.cpp:485-510
     if (j.contains("_data")) {
         Tokens t(j["_data"].str());
@@ -394,7 +478,9 @@ void parse_faces(rtx_host_scene& s, const Json& j, std::vector<int32_t>& faces) 
             faces.push_back((int32_t)(a - 1)); faces.push_back((int32_t)(b - 1)); faces.push_back((int32_t)(c - 1));
         }
     } else if (j.contains("_plyFile")) {
-        rtxhost::PlyMesh pm = rtxhost::read_ply(s.base_dir + j["_plyFile"].str());   // scene.cpp:699-733
+        const std::string ply_path = s.base_dir + j["_plyFile"].str();
+        s.files.push_back(file_stamp(ply_path));
+        rtxhost::PlyMesh pm = rtxhost::read_ply(ply_path);                            // scene.cpp:699-733
         size_t base = s.vertices.size() / 3;
         faces.resize(pm.tri.size());
         for (size_t i = 0; i < pm.tri.size(); i++) faces[i] = (int32_t)(base + (size_t)pm.tri[i]);
@@ -529,26 +615,9 @@ void load(rtx_host_scene& s, const std::string& path, bool use_bvh, bool cull) {
     d.shadow_ray_epsilon = sc.has("ShadowRayEpsilon") ? parse_double(sc["ShadowRayEpsilon"].str()) : (double)0.001f;
     d.intersection_test_epsilon = sc.has("IntersectionTestEpsilon") ? parse_double(sc["IntersectionTestEpsilon"].str()) : (double)1e-10f;
 
-    if (sc.has("Cameras"))
-        for_each_item(sc["Cameras"]["Camera"], [&](const Json& j) {
-            unsigned id; HostCamera c = parse_camera(j, id);
-            if (id != 0) s.cameras.push_back(c);
-        });
-    if (sc.has("Lights")) {
-        const Json& L = sc["Lights"];
-        if (L.has("AmbientLight")) put(d.ambient, parse_v3(L["AmbientLight"].str()));
-        if (L.has("PointLight"))
-            for_each_item(L["PointLight"], [&](const Json& j) {
-                unsigned id = (unsigned)parse_long(j["_id"].str());
-                rtx_light l{};
-                put(l.position, parse_v3(j["Position"].str()));
-                put(l.intensity, parse_v3(j["Intensity"].str()));
-                if (id != 0) {
-                    s.lights.push_back(l);
-                    s.light_tf.push_back(j.has("Transformations") ? parse_trefs(j["Transformations"].str()) : std::vector<TRef>());
-                }
-            });
-    }
+    s.use_bvh = use_bvh; s.cull = cull;
+    parse_view(s, sc);
+    if (sc.has("Lights") && sc["Lights"].has("AmbientLight")) put(d.ambient, parse_v3(sc["Lights"]["AmbientLight"].str()));
     if (sc.has("Materials"))
         for_each_item(sc["Materials"]["Material"], [&](const Json& j) {
             unsigned id; rtx_material m = parse_material(j, id);
@@ -702,21 +771,7 @@ void load(rtx_host_scene& s, const std::string& path, bool use_bvh, bool cull) {
             in.xform = s.add_xform(fin, &world);
         }
     }
-    for (HostCamera& hc : s.cameras)                                     // scene.cpp:971-979
-        if (!hc.tf.empty()) {
-            Mat4 M = s.object_matrix(hc.tf);
-            rtx_camera& c = hc.cam;
-            V3 p = xf_point(M, {c.position[0], c.position[1], c.position[2]});
-            V3 g = normalize(xf_dir(M, {c.gaze[0], c.gaze[1], c.gaze[2]}));
-            V3 u = normalize(xf_dir(M, {c.up[0], c.up[1], c.up[2]}));
-            put(c.position, p); put(c.gaze, g); put(c.up, u);
-        }
-    for (size_t i = 0; i < s.lights.size(); i++)                         // scene.cpp:981-987
-        if (!s.light_tf[i].empty()) {
-            Mat4 M = s.object_matrix(s.light_tf[i]);
-            rtx_light& l = s.lights[i];
-            put(l.position, xf_point(M, {l.position[0], l.position[1], l.position[2]}));
-        }
+    transform_view(s);
     for (HostMesh& m : s.meshes) if (m.smooth) vertex_normals(s, m);
     auto t2 = std::chrono::high_resolution_clock::now();
     s.parse_ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
@@ -746,6 +801,33 @@ void load(rtx_host_scene& s, const std::string& path, bool use_bvh, bool cull) {
     d.triangles = s.triangles.data(); d.n_triangles = (int32_t)s.triangles.size();
     d.meshes = s.mesh_desc.data(); d.n_meshes = (int32_t)s.mesh_desc.size();
     d.instances = s.inst_desc.data(); d.n_instances = (int32_t)s.inst_desc.size();
+    s.geometry_doc = geometry_part(sc);
+}
+
+// Next frame of an animation: when `path` describes the geometry `s` already holds (same
+// document apart from cameras and point lights, same directory, PLY files untouched), only
+// its cameras and lights are taken.  Returns false, leaving `s` alone, when it does not.
+bool load_view_only(rtx_host_scene& s, const std::string& path) {
+    auto t0 = std::chrono::high_resolution_clock::now();
+    std::ifstream file(path, std::ios::binary);
+    if (!file.is_open()) throw std::runtime_error("Error: The json file cannot be loaded.");
+    size_t slash = path.find_last_of("/\\");
+    if ((slash == std::string::npos ? "" : path.substr(0, slash + 1)) != s.base_dir) return false;
+    std::string text((std::istreambuf_iterator<char>(file)), std::istreambuf_iterator<char>());
+    Json root = Json::parse(text);
+    if (!root.contains("Scene")) throw std::runtime_error("Error: Scene root is not found.");
+    const Json& sc = root["Scene"];
+    if (!same_json(geometry_part(sc), s.geometry_doc)) return false;
+    for (const rtx_host_scene::FileStamp& f : s.files) {
+        const rtx_host_scene::FileStamp now = file_stamp(f.path);
+        if (now.size != f.size || now.mtime_ns != f.mtime_ns) return false;
+    }
+    parse_view(s, sc);
+    transform_view(s);
+    s.desc.lights = s.lights.data(); s.desc.n_lights = (int32_t)s.lights.size();
+    s.parse_ms = std::chrono::duration<double, std::milli>(std::chrono::high_resolution_clock::now() - t0).count();
+    s.preprocess_ms = 0.0;
+    return true;
 }
 
 // ---- dump: same sections as the reference-side dumper used by the tests ----------------
@@ -897,6 +979,31 @@ int rtx_host_load(const char* json_path, int use_bvh, int enable_cull, rtx_host_
         delete s;
         return -1;
     }
+}
+
+int rtx_host_load_next(const char* json_path, rtx_host_scene* prev, rtx_host_scene** out, int* reused) {
+    if (!json_path || !out) { g_error = "rtx_host_load_next: null argument"; return -1; }
+    if (reused) *reused = 0;
+    if (prev) {
+        try {
+            if (load_view_only(*prev, json_path)) {
+                *out = prev;
+                if (reused) *reused = 1;
+                return 0;
+            }
+        } catch (const std::exception& e) {
+            g_error = e.what();
+            return -1;
+        }
+        const int use_bvh = prev->use_bvh, cull = prev->cull;
+        rtx_host_scene* fresh = nullptr;
+        if (rtx_host_load(json_path, use_bvh, cull, &fresh) != 0) return -1;   // prev stays valid
+        delete prev;
+        *out = fresh;
+        return 0;
+    }
+    g_error = "rtx_host_load_next: no previous scene (use rtx_host_load for the first frame)";
+    return -1;
 }
 
 const rtx_scene_desc* rtx_host_desc(const rtx_host_scene* s) { return s ? &s->desc : nullptr; }

@@ -14,15 +14,95 @@
 // For every camera it writes <out>/<ImageName stem>.ppm (ASCII P3, byte-identical layout to
 // scene.cpp:675-697), optionally a .png, and <stem>_results.json with the reference's keys
 // (raytracer.cpp:269-282) plus device timings.
+//
+// Several scene files form an animation (the reference renders them one process per frame,
+// runner.py:105-141).  Here they go through one pipeline: a frame whose geometry equals its
+// predecessor's keeps the loaded scene and its device copy and only takes over cameras and
+// lights (rtx_host_load_next + rtx_scene_update_lights), and pictures are encoded and
+// written by a second thread while the next frame renders.
+#include <atomic>
 #include <chrono>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "rtx_amd.h"
 #include "rtx_host.h"
+
+namespace {
+
+// One finished picture on its way to disk.
+struct OutputJob {
+    std::string base, stem, results;
+    std::vector<uint8_t> img;
+    int width = 0, height = 0;
+    bool png = false;
+};
+
+// Writes pictures in the background; at most kDepth of them wait (each is a full frame).
+class Writer {
+public:
+    Writer() : worker_([this] { run(); }) {}
+    ~Writer() { finish(); }
+    void push(OutputJob&& job) {
+        std::unique_lock<std::mutex> lk(m_);
+        room_.wait(lk, [this] { return queue_.size() < kDepth; });
+        queue_.push_back(std::move(job));
+        work_.notify_one();
+    }
+    bool finish() {                       // true when every file was written
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            if (done_) return !failed_;
+            done_ = true;
+        }
+        work_.notify_one();
+        worker_.join();
+        return !failed_;
+    }
+
+private:
+    static constexpr size_t kDepth = 3;
+    void run() {
+        while (true) {
+            OutputJob job;
+            {
+                std::unique_lock<std::mutex> lk(m_);
+                work_.wait(lk, [this] { return !queue_.empty() || done_; });
+                if (queue_.empty()) return;
+                job = std::move(queue_.front());
+                queue_.pop_front();
+                room_.notify_one();
+            }
+            if (rtx_host_write_ppm(job.base.c_str(), job.img.data(), job.width, job.height) != 0) {
+                fprintf(stderr, "%s\n", rtx_host_last_error());
+                failed_ = true;
+            }
+            if (job.png && rtx_host_write_png((job.stem + ".png").c_str(), job.img.data(), job.width, job.height) != 0) {
+                fprintf(stderr, "%s\n", rtx_host_last_error());
+                failed_ = true;
+            }
+            if (FILE* f = fopen((job.stem + "_results.json").c_str(), "w")) {
+                fputs(job.results.c_str(), f);
+                fclose(f);
+            }
+        }
+    }
+    std::mutex m_;
+    std::condition_variable work_, room_;
+    std::deque<OutputJob> queue_;
+    bool done_ = false;
+    std::atomic<bool> failed_{false};
+    std::thread worker_;
+};
+
+}  // namespace
 
 int main(int argc, char** argv) {
     std::vector<std::string> scenes;
@@ -50,60 +130,83 @@ int main(int argc, char** argv) {
     }
     (void)multithreaded;
     int rc_all = 0;
+    Writer writer;
+    rtx_host_scene* hs = nullptr;
+    rtx_scene* ds = nullptr;
+    double upload_ms = 0;
     for (size_t si = 0; si < scenes.size(); si++) {
         if ((int)(si % (size_t)shard_n) != shard_r) continue;
-        rtx_host_scene* hs = nullptr;
-        if (rtx_host_load(scenes[si].c_str(), use_bvh, cull, &hs) != 0) {
+        int reused = 0;
+        if (hs) {
+            rtx_host_scene* next = nullptr;
+            if (rtx_host_load_next(scenes[si].c_str(), hs, &next, &reused) != 0) {
+                fprintf(stderr, "%s: %s\n", scenes[si].c_str(), rtx_host_last_error());
+                rc_all = 1;
+                continue;                                    // the previous scene stays loaded
+            }
+            hs = next;
+        } else if (rtx_host_load(scenes[si].c_str(), use_bvh, cull, &hs) != 0) {
             fprintf(stderr, "%s: %s\n", scenes[si].c_str(), rtx_host_last_error());
             rc_all = 1;
+            hs = nullptr;
             continue;
         }
         double parse_ms = 0, pre_ms = 0;
         rtx_host_timings(hs, &parse_ms, &pre_ms);
-        auto t0 = std::chrono::high_resolution_clock::now();
-        rtx_scene* ds = nullptr;
-        if (rtx_scene_create(rtx_host_desc(hs), device, &ds) != RTX_OK) {
-            fprintf(stderr, "%s: %s\n", scenes[si].c_str(), rtx_last_error());
-            rtx_host_free(hs);
-            return 1;                                        // no device: nothing else can work either
+        const rtx_scene_desc* desc = rtx_host_desc(hs);
+        if (reused && ds) {
+            upload_ms = 0;
+            if (rtx_scene_update_lights(ds, desc->lights, desc->n_lights) != RTX_OK) {
+                fprintf(stderr, "%s: %s\n", scenes[si].c_str(), rtx_last_error());
+                rc_all = 1;
+                continue;
+            }
+        } else {
+            if (ds) { rtx_scene_destroy(ds); ds = nullptr; }
+            auto t0 = std::chrono::high_resolution_clock::now();
+            if (rtx_scene_create(desc, device, &ds) != RTX_OK) {
+                fprintf(stderr, "%s: %s\n", scenes[si].c_str(), rtx_last_error());
+                rtx_host_free(hs);
+                return 1;                                    // no device: nothing else can work either
+            }
+            upload_ms = std::chrono::duration<double, std::milli>(std::chrono::high_resolution_clock::now() - t0).count();
         }
-        double upload_ms = std::chrono::duration<double, std::milli>(std::chrono::high_resolution_clock::now() - t0).count();
         double total_ms = pre_ms;
         for (int k = 0; k < rtx_host_camera_count(hs); k++) {
             rtx_camera cam;
             char name[512];
             rtx_host_camera(hs, k, &cam, name, sizeof name);
-            std::vector<uint8_t> img((size_t)cam.width * cam.height * 3);
+            OutputJob job;
+            job.img.resize((size_t)cam.width * cam.height * 3);
             rtx_stats st;
-            if (rtx_render(ds, &cam, cam.width, cam.height, 0, 1, img.data(), 0, nullptr, &st) != RTX_OK) {
+            if (rtx_render(ds, &cam, cam.width, cam.height, 0, 1, job.img.data(), 0, nullptr, &st) != RTX_OK) {
                 fprintf(stderr, "%s: %s\n", scenes[si].c_str(), rtx_last_error());
                 rc_all = 1;
                 break;
             }
             total_ms += st.total_ms;
-            std::string base = out_dir + name;
-            if (rtx_host_write_ppm(base.c_str(), img.data(), cam.width, cam.height) != 0) {
-                fprintf(stderr, "%s\n", rtx_host_last_error());
-                rc_all = 1;
-            }
-            std::string stem = base.substr(0, base.find_last_of('.'));
-            if (png) rtx_host_write_png((stem + ".png").c_str(), img.data(), cam.width, cam.height);
-            FILE* f = fopen((stem + "_results.json").c_str(), "w");
-            if (f) {
-                fprintf(f, "{\n    \"enableBackFaceCulling\": %s,\n    \"isMultiThreaded\": %s,\n"
-                           "    \"preprocessingTimeMs\": %.3f,\n    \"renderTimeMs\": %.3f,\n    \"sceneName\": \"%s\",\n"
-                           "    \"totalTimeMs\": %.3f,\n    \"useBVH\": %s,\n    \"device\": \"hip:%d\",\n"
-                           "    \"kernelTimeMs\": %.3f,\n    \"parseTimeMs\": %.3f,\n    \"uploadTimeMs\": %.3f\n}",
-                        cull ? "true" : "false", multithreaded ? "true" : "false", pre_ms, st.total_ms, name, total_ms,
-                        use_bvh ? "true" : "false", device, st.kernel_ms, parse_ms, upload_ms);
-                fclose(f);
-            }
+            job.base = out_dir + name;
+            job.stem = job.base.substr(0, job.base.find_last_of('.'));
+            job.width = cam.width; job.height = cam.height; job.png = png;
+            char buf[1024];
+            snprintf(buf, sizeof buf,
+                     "{\n    \"enableBackFaceCulling\": %s,\n    \"isMultiThreaded\": %s,\n"
+                     "    \"preprocessingTimeMs\": %.3f,\n    \"renderTimeMs\": %.3f,\n    \"sceneName\": \"%s\",\n"
+                     "    \"totalTimeMs\": %.3f,\n    \"useBVH\": %s,\n    \"device\": \"hip:%d\",\n"
+                     "    \"kernelTimeMs\": %.3f,\n    \"parseTimeMs\": %.3f,\n    \"uploadTimeMs\": %.3f,\n"
+                     "    \"geometryReused\": %s\n}",
+                     cull ? "true" : "false", multithreaded ? "true" : "false", pre_ms, st.total_ms, name, total_ms,
+                     use_bvh ? "true" : "false", device, st.kernel_ms, parse_ms, upload_ms, reused ? "true" : "false");
+            job.results = buf;
+            writer.push(std::move(job));
             if (!quiet)
-                printf("%s: %dx%d rendered in %.3f ms (kernels %.3f ms), preprocess %.1f ms, upload %.1f ms\n", name,
-                       cam.width, cam.height, st.total_ms, st.kernel_ms, pre_ms, upload_ms);
+                printf("%s: %dx%d rendered in %.3f ms (kernels %.3f ms), parse %.1f ms, preprocess %.1f ms, upload %.1f ms%s\n",
+                       name, cam.width, cam.height, st.total_ms, st.kernel_ms, parse_ms, pre_ms, upload_ms,
+                       reused ? " (geometry kept)" : "");
         }
-        rtx_scene_destroy(ds);
-        rtx_host_free(hs);
     }
+    if (ds) rtx_scene_destroy(ds);
+    if (hs) rtx_host_free(hs);
+    if (!writer.finish()) rc_all = 1;
     return rc_all;
 }

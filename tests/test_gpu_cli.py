@@ -1,0 +1,80 @@
+"""The command-line host on the GPU: the reference's flags and output files
+(raytracer.cpp:173-282), and the animation pipeline behind several scene files (geometry kept
+from frame to frame, pictures written in the background)."""
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import _checkers as ck
+import raytracer_amd as rt
+from raytracer_amd import scenes
+
+pytestmark = pytest.mark.gpu
+
+CLI = os.path.join(ck.ROOT, "raytracer_amd", "lib", "raytracer_amd")
+
+
+def read_p3(path):
+    tok = open(path).read().split()
+    assert tok[0] == "P3" and tok[3] == "255"
+    w, h = int(tok[1]), int(tok[2])
+    return np.array(tok[4:], dtype=np.int32).reshape(h, w, 3).astype(np.uint8)
+
+
+def run_cli(args):
+    r = subprocess.run([CLI] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    return r.stdout
+
+
+def test_animation_pipeline_equals_frame_by_frame_runs(tmp_path):
+    d = str(tmp_path)
+    n = 5
+    frames = [scenes.scene_david_frame(d, f, n_frames=12, faces=5000, res=(96, 80)) for f in range(n)]
+    # frame 3 is a different scene (another material): the pipeline must reload there
+    doc = json.load(open(frames[3]))
+    doc["Scene"]["Materials"]["Material"][1]["DiffuseReflectance"] = "0.2 0.7 0.3"
+    json.dump(doc, open(frames[3], "w"))
+    together, single = os.path.join(d, "together"), os.path.join(d, "single")
+    os.makedirs(together); os.makedirs(single)
+    out = run_cli(frames + ["--out", together, "--png"])
+    assert out.count("geometry kept") == 2                       # frames 1, 2 (4 reloads after 3)
+    for f in frames:
+        run_cli([f, "--out", single, "--quiet"])
+    for k in range(n):
+        stem = f"davids_camera_{k:03d}"
+        a, b = read_p3(os.path.join(together, stem + ".ppm")), read_p3(os.path.join(single, stem + ".ppm"))
+        same, mx = ck.image_diff(a, b)
+        assert mx <= 1 and same >= 0.999, (k, same, mx)
+        res = json.load(open(os.path.join(together, stem + "_results.json")))
+        assert res["geometryReused"] == (k in (1, 2))
+        assert res["useBVH"] is True and res["enableBackFaceCulling"] is False
+        assert os.path.getsize(os.path.join(together, stem + ".png")) > 0
+        # and the picture is the library's own rendering of that file
+        rgb, _ = rt.render_file(frames[k])
+        same, mx = ck.image_diff(a, rgb)
+        assert mx <= 1 and same >= 0.999
+    assert not np.array_equal(read_p3(os.path.join(together, "davids_camera_000.ppm")),
+                              read_p3(os.path.join(together, "davids_camera_001.ppm")))
+
+
+def test_sharded_animation_covers_every_frame_once(tmp_path):
+    d = str(tmp_path)
+    frames = [scenes.scene_david_frame(d, f, n_frames=12, faces=2000, res=(48, 40)) for f in range(5)]
+    outs = []
+    for r in range(2):
+        o = os.path.join(d, f"rank{r}")
+        os.makedirs(o)
+        run_cli(frames + ["--out", o, "--shard", f"{r}/2", "--quiet"])
+        outs.append(sorted(x for x in os.listdir(o) if x.endswith(".ppm")))
+    assert outs[0] == [f"davids_camera_{k:03d}.ppm" for k in (0, 2, 4)]
+    assert outs[1] == [f"davids_camera_{k:03d}.ppm" for k in (1, 3)]
+
+
+def test_cli_reports_bad_input(tmp_path):
+    r = subprocess.run([CLI, os.path.join(str(tmp_path), "missing.json"), "--out", str(tmp_path)],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=60)
+    assert r.returncode != 0 and "cannot be loaded" in r.stderr

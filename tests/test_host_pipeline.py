@@ -122,3 +122,65 @@ def test_ppm_and_png_writers(tmp_path):
     from PIL import Image
     back = np.asarray(Image.open(str(tmp_path / "img2.png")))
     assert np.array_equal(back, rgb)
+
+
+def _cam_bytes(hs, k=0):
+    import ctypes as C
+    cam, name = hs.camera(k)
+    return bytes(C.string_at(C.byref(cam), C.sizeof(cam))), name
+
+
+def test_next_frame_reuses_geometry_when_only_view_changes(tmp_path):
+    """Animation frames (runner.py:105-141 renders them one process each): a frame that differs
+    from its predecessor only in cameras and point lights keeps the loaded geometry; its
+    cameras and lights must equal those of a full load of the same file."""
+    import ctypes as C
+    import json
+    d = str(tmp_path)
+    frames = [scenes.scene_david_frame(d, f, n_frames=12, faces=2000, res=(48, 48)) for f in range(3)]
+    # frame 2 also moves a light (through a transformation) and dims it
+    doc = json.load(open(frames[2]))
+    doc["Scene"]["Transformations"] = {"Translation": [{"_id": "1", "_data": "0 1 0"}]}
+    json.dump(doc, open(frames[2], "w"))
+    for f in (0, 1):            # the same Transformations block in every frame, or geometry differs
+        dd = json.load(open(frames[f]))
+        dd["Scene"]["Transformations"] = doc["Scene"]["Transformations"]
+        json.dump(dd, open(frames[f], "w"))
+    doc["Scene"]["Lights"]["PointLight"][0]["Transformations"] = "t1"
+    doc["Scene"]["Lights"]["PointLight"][1]["Intensity"] = "7000 7000 7000"
+    json.dump(doc, open(frames[2], "w"))
+
+    hs = rt.HostScene(frames[0])
+    geometry = C.addressof(hs.desc.contents.meshes.contents)
+    for f in (1, 2):
+        assert hs.load_next(frames[f]) is True
+        fresh = rt.HostScene(frames[f])
+        assert _cam_bytes(hs) == _cam_bytes(fresh)
+        a, b = hs.lights(), fresh.lights()
+        assert len(a) == len(b) == 2
+        for x, y in zip(a, b):
+            assert list(x.position) == list(y.position) and list(x.intensity) == list(y.intensity)
+        assert C.addressof(hs.desc.contents.meshes.contents) == geometry      # nothing was rebuilt
+        assert hs.timings()["preprocess_ms"] == 0.0
+        fresh.close()
+    assert hs.lights()[0].position[1] == 10.0                                  # 9 + the translation
+
+    # a changed material is a different scene: full reload, same flags
+    doc = json.load(open(frames[1]))
+    doc["Scene"]["Materials"]["Material"][1]["PhongExponent"] = "31"
+    other = os.path.join(d, "other.json")
+    json.dump(doc, open(other, "w"))
+    assert hs.load_next(other) is False
+    assert hs.desc.contents.materials[1].phong_exponent == 31.0
+    # ... and so is an untouched document whose PLY file changed on disk
+    assert hs.load_next(frames[1]) is False
+    ply = os.path.join(d, "davids_camera_mesh.ply")
+    st = os.stat(ply)
+    os.utime(ply, ns=(st.st_atime_ns, st.st_mtime_ns + 1_000_000_000))
+    assert hs.load_next(frames[0]) is False
+    assert hs.load_next(frames[1]) is True
+    # errors leave the loaded scene usable
+    with pytest.raises(rt.RtxError):
+        hs.load_next(os.path.join(d, "missing.json"))
+    assert hs.n_cameras == 1
+    hs.close()
