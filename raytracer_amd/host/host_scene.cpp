@@ -1042,16 +1042,30 @@ int rtx_host_write_ppm(const char* path, const uint8_t* rgb, int width, int heig
     FILE* f = fopen(fn.c_str(), "w");
     if (!f) { g_error = "Error: The ppm file cannot be opened for writing: " + std::string(path); return -1; }
     fprintf(f, "P3\n%d %d\n255\n", width, height);
-    std::string row;
-    char buf[8];
+    // "<value> " per channel, one text row per image row; the 256 possible pieces are
+    // prepared once (a 4K frame is 25 million of them)
+    char piece[256][4];
+    unsigned char piece_len[256];
+    for (int v = 0; v < 256; v++) {
+        int n = 0;
+        if (v >= 100) piece[v][n++] = (char)('0' + v / 100);
+        if (v >= 10) piece[v][n++] = (char)('0' + v / 10 % 10);
+        piece[v][n++] = (char)('0' + v % 10);
+        piece[v][n++] = ' ';
+        for (int k = n; k < 4; k++) piece[v][k] = ' ';
+        piece_len[v] = (unsigned char)n;
+    }
+    std::vector<char> row((size_t)width * 3 * 4 + 4);
     for (int y = 0; y < height; y++) {
-        row.clear();
+        char* o = row.data();
+        const uint8_t* src = rgb + (size_t)y * width * 3;
         for (int x = 0; x < width * 3; x++) {
-            int n = snprintf(buf, sizeof buf, "%u ", (unsigned)rgb[(size_t)y * width * 3 + x]);
-            row.append(buf, (size_t)n);
+            const unsigned v = src[x];
+            memcpy(o, piece[v], 4);
+            o += piece_len[v];
         }
-        row += '\n';
-        fwrite(row.data(), 1, row.size(), f);
+        *o++ = '\n';
+        fwrite(row.data(), 1, (size_t)(o - row.data()), f);
     }
     fputc('\n', f);
     fclose(f);

@@ -111,13 +111,14 @@ def test_single_object_and_array_forms_are_equivalent(tmp_path):
 
 
 def test_ppm_and_png_writers(tmp_path):
-    rgb = (np.arange(5 * 7 * 3) % 256).astype(np.uint8).reshape(5, 7, 3)
+    rgb = (np.arange(15 * 17 * 3) % 256).astype(np.uint8).reshape(15, 17, 3)      # every byte value
     rt.write_ppm(str(tmp_path / "img.png"), rgb)            # extension is replaced, as the reference does
     text = (tmp_path / "img.ppm").read_text()
     lines = text.split("\n")
-    assert lines[0] == "P3" and lines[1] == "7 5" and lines[2] == "255"
-    assert lines[3] == " ".join(str(int(v)) for v in rgb[0].reshape(-1)) + " "
-    assert text.endswith("\n\n")
+    assert lines[0] == "P3" and lines[1] == "17 15" and lines[2] == "255"
+    for y in range(15):
+        assert lines[3 + y] == " ".join(str(int(v)) for v in rgb[y].reshape(-1)) + " "
+    assert text.endswith("\n\n") and len(lines) == 3 + 15 + 2
     rt.write_png(str(tmp_path / "img2.png"), rgb)
     from PIL import Image
     back = np.asarray(Image.open(str(tmp_path / "img2.png")))
