@@ -497,7 +497,7 @@ RTX_DEV void ray_begin(const Scene& S, Lane& L, const RecOut& out, Tally& tl) {
 // up: rayHitsMesh's prologue, utils.cpp:418-494 + the root test of bvh.cpp:132) or the
 // object sequence is exhausted (returns false).
 template <bool COUNT>
-RTX_DEV bool job_next(const Scene& S, Lane& L, const RecOut& out, unsigned* inst_bits, Tally& tl) {
+RTX_DEV bool job_next(const Scene& S, Lane& L, const RecOut& out, unsigned* inst_bits, const double light_dist, Tally& tl) {
     const RTX_GLOBAL Obj* const objs = (const RTX_GLOBAL Obj*)S.objs;
     const unsigned n_summary = rtx_summary_words(S.n_insts);
     const Slab ws = make_slab(L.o, L.d);         // world-space slab constants, once per call
@@ -536,6 +536,7 @@ RTX_DEV bool job_next(const Scene& S, Lane& L, const RecOut& out, unsigned* inst
                     double enter;
                     if (box_enter(tl_min, tl_max, ws, enter) && (L.t_min >= enter)) {
                         L.obj = -1;                                  // marks the job as the TLAS walk
+                        L.is_shadow &= 1;
                         L.orig_t_min = L.t_min;
                         L.ro = L.o; L.rd = L.d; L.ix = ws.ix; L.iy = ws.iy; L.iz = ws.iz; L.par = ws.par;
                         L.cur_ref = S.tl_key; L.cur_cnt = 0; L.sp = 0; L.btri = -1;
@@ -590,6 +591,20 @@ RTX_DEV bool job_next(const Scene& S, Lane& L, const RecOut& out, unsigned* inst
         if (!box_enter(ob2 + 6, ob2 + 9, sl, enter) || !(L.t_min >= enter)) continue;
         L.obj = oi;
         L.orig_t_min = L.t_min;
+        L.is_shadow &= 1;
+        if (!COUNT && L.is_shadow && !(flags & OBJ_XF)) {
+            // A shadow ray asks only whether something lies in front of the light
+            // (utils.cpp:1066-1084: hit && distance < |L - P|).  Once a hit has been accepted
+            // with the bound below that distance the answer is yes whatever follows: the bound
+            // never grows, every later write to the record's distance is below the bound of
+            // its moment, and the hit flag is never taken back.  In an untransformed mesh an
+            // accepted triangle is such a hit, so the job may stop there (bit 1 of is_shadow;
+            // orig_t_min, unused by untransformed jobs, carries the light's distance).
+            // Transformed jobs decide acceptance only at their end (utils.cpp:559-570).
+            // With counters on every test of the reference is carried out.
+            L.is_shadow = 3;
+            L.orig_t_min = light_dist;
+        }
         L.ro = ro; L.rd = rd; L.ix = sl.ix; L.iy = sl.iy; L.iz = sl.iz; L.par = sl.par;
         L.cur_ref = root_ref; L.cur_cnt = root_count; L.sp = 0; L.btri = -1;
         return true;
@@ -825,7 +840,13 @@ RTX_DEV void service_lane(const Launch* __restrict__ Lp, const int gen, double* 
         L.state = LS_NEED_JOB;
         if (COUNT) { const long long c = clock64(); tl.sec[1] += (unsigned long long)(c - c0); tl.sec[5]++; c0 = c; }
     }
-    const bool more = job_next<COUNT>(S, L, out, inst_bits, tl);
+    // A shadow ray with an accepted hit in front of its light is decided (see job_next).  It is
+    // retired here only while its instance candidates have not been collected yet: the lane's
+    // candidate bitmap must be clear when the next ray starts.
+    double light_dist = 0.0;
+    if (!COUNT && L.is_shadow) light_dist = ((const RTX_GLOBAL Ray*)qin.rays + slot)->aux;
+    const bool decided = !COUNT && L.is_shadow && L.hit != 0 && L.t_min < light_dist && L.it <= S.n_meshes;
+    const bool more = !decided && job_next<COUNT>(S, L, out, inst_bits, light_dist, tl);
     if (COUNT) { const long long c = clock64(); tl.sec[2] += (unsigned long long)(c - c0); tl.sec[6]++; c0 = c; }
     if (more) { L.state = LS_IN_JOB; return; }
     // ---- ray complete ------------------------------------------------------------------------
@@ -1022,6 +1043,9 @@ RTX_DEV void traverse_steps(const Scene& S, const Wave& wv, Lane& L, glob_v4i* _
                 if (two && !culled1 && tri_test(tq, L.ro, L.rd, L.t_min, isect_eps, t, b, g2)) { L.t_min = t; L.btri = ti + 1; }
                 L.cur_ref += 2; L.cur_cnt -= 2;
                 need_pop = L.cur_cnt <= 0;
+                if (!COUNT && (L.is_shadow & 2) && L.btri >= 0 && L.t_min < L.orig_t_min) {
+                    need_pop = true; L.sp = 0;         // occluder found: the job ends here
+                }
             }
         }
         __builtin_amdgcn_wave_barrier();

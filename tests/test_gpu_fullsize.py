@@ -58,6 +58,11 @@ def test_full_size_scene_matches_oracle_on_reduced_view(workloads, name, factor)
     assert mx <= MAX_DELTA and same >= MIN_SAME, f"{name}: {same:.5f} identical, max delta {mx}"
     for k in ("rays", "primary_rays", "shadow_rays", "secondary_rays", "tri_tests"):
         assert st[k] == o_ctr[k], (k, st[k], o_ctr[k])
+    # the default mode (counters off: occluded shadow rays retire early) gives the same results
+    rgb2, hits2, _ = ds.render(small, want_hits=True)
+    assert len(ck.compare_hits(hits2, o_hits, allow_src_unknown=False)) == 0
+    same, mx = ck.image_diff(rgb2, o_rgb)
+    assert mx <= MAX_DELTA and same >= MIN_SAME, f"{name} (default mode): {same:.5f} identical, max delta {mx}"
 
 
 @pytest.mark.parametrize("name,tile", [("dragon_metal", (64, 64)), ("grass_desert", (128, 72))])
