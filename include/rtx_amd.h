@@ -194,7 +194,12 @@ int rtx_unpack_tiles(const uint8_t* packed, int32_t width, int32_t height,
                      int32_t tile_w, int32_t tile_h, int32_t tile_first, int32_t tile_stride,
                      uint8_t* frame);
 
-/* Collect per-ray work counters in rtx_stats (slower kernels); default off. */
+/* Collect per-ray work counters in rtx_stats (slower kernels); default off.
+ * With counters on, the device carries out every closest-hit query to its end, so that ray
+ * and triangle-test counts equal those of the reference's algorithm (utils.cpp:671-865).
+ * With counters off, a shadow ray (isInShadow, utils.cpp:1066-1084) is retired at the first
+ * accepted hit that lies in front of its light: the answer `hit && distance < |L - P|` can
+ * no longer change after that, so pictures and hit records are the same in both modes. */
 int rtx_scene_set_counters(rtx_scene* scene, int32_t enable);
 
 /* Cap, in bytes, of the two ray queues together (default 32 GiB). */
