@@ -209,7 +209,7 @@ typedef __attribute__((address_space(1))) v4i glob_v4i;
 struct Wave { lds_double* rows; unsigned lane; };
 
 // Wave-cooperative gather of one 256-byte record per requesting lane into that lane's LDS row.
-// `mask` = ballot of the requesting lanes; `key` names the record by its offset in 128-byte
+// `key` names the record by its offset in 128-byte
 // units from `blas` (-1 = no request): a collapsed node, or a pair of triangle records.
 //
 // Sixteen lanes read one record as sixteen adjacent 16-byte pieces, so one load instruction
@@ -223,7 +223,7 @@ struct Wave { lds_double* rows; unsigned lane; };
 // here and to the slot index in row_read.  Must be executed by every lane of the wave.
 typedef __attribute__((address_space(3))) int lds_int;
 typedef __attribute__((address_space(3))) v4i lds_v4i;
-RTX_DEV void coop_fetch(const Wave& wv, unsigned long long mask, int key, const char* __restrict__ blas) {
+RTX_DEV void coop_fetch(const Wave& wv, int key, const char* __restrict__ blas) {
     const unsigned lane = wv.lane, quarter = lane >> 4, slot = lane & 15u;
     ((lds_int*)wv.rows)[(lane & 3u) * 16u + (lane >> 2)] = key;
     __builtin_amdgcn_wave_barrier();
@@ -239,16 +239,27 @@ RTX_DEV void coop_fetch(const Wave& wv, unsigned long long mask, int key, const 
     // the keys must have left the row memory before the first record lands in it
     __builtin_amdgcn_s_waitcnt(0xC07F);          // lgkmcnt(0); vmcnt and expcnt left at "no wait"
     __builtin_amdgcn_wave_barrier();
+    // Source address of this lane's piece in round g: piece = slot ^ ((4g + quarter) & 15)
+    // = (slot ^ quarter) ^ 4(g & 3), so four per-lane bases cover the sixteen rounds; the record
+    // offset is key * 128, formed together with the base by one 32x32+64-bit multiply-add (the
+    // factor is kept opaque so that it is not split into a 64-bit shift and a 64-bit add).
+    unsigned unit = 128u;
+    asm volatile("" : "+s"(unit));
+    // (likewise the rows' LDS address: sixteen round destinations computed here with one scalar
+    // add each, instead of sixteen loop-invariant values that would have to live in registers)
+    unsigned rows_at = (unsigned)(size_t)wv.rows;
+    asm volatile("" : "+s"(rows_at));
+    unsigned long long base[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) base[j] = (unsigned long long)blas + (((slot ^ quarter) ^ (4u * j)) << 4);
 #pragma unroll
     for (int g = 0; g < 16; g++) {
-        // (wave-uniform skip: in a sparsely occupied wave most rounds have no requester)
-        if (((unsigned)(mask >> (4 * g)) & 0xFu) == 0u) continue;
+        // (a round none of whose four owners requests anything has no lane to execute it)
         const int okey = okeys[g];
-        const unsigned piece = slot ^ ((4u * g + quarter) & 15u);
         if (okey != -1) {
-            const char* gp = blas + ((size_t)(unsigned)okey << 7) + (piece << 4);
+            const unsigned long long gp = base[g & 3] + (unsigned long long)(unsigned)okey * unit;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gp,
-                                             (__attribute__((address_space(3))) void*)(wv.rows + g * 4 * RTX_ROW_DOUBLES),
+                                             (__attribute__((address_space(3))) void*)(size_t)(rows_at + (unsigned)g * (4u * RTX_ROW_DOUBLES * 8u)),
                                              16, 0, 0);
         }
     }
@@ -960,7 +971,7 @@ RTX_DEV void traverse_steps(const Scene& S, const Wave& wv, Lane& L, glob_v4i* _
                 for (int p = 0; p < 16; p++) { const v2d v = gp[p]; rec[2 * p] = v.x; rec[2 * p + 1] = v.y; }
             }
         } else {
-            coop_fetch(wv, m_job, in_job ? L.cur_ref : -1, blas);
+            coop_fetch(wv, in_job ? L.cur_ref : -1, blas);
             if (in_job) row_read<0, 16>(wv, rec);
             __builtin_amdgcn_wave_barrier();
         }
