@@ -1074,12 +1074,33 @@ RTX_DEV void traverse_steps(const Scene& S, const Wave& wv, Lane& L, glob_v4i* _
                 --L.sp;
                 L.top = stk[L.sp > 0 ? L.sp - 1 : 0];          // (entry 0 is always readable)
                 if (!pass) {
+                    // The entry failed its re-check.  After a hit has pulled the bound in, most of
+                    // what is left on the stack fails too, one entry after the other: the entries
+                    // are examined four at a time (adjacent in memory, one round trip; the first
+                    // of them is the refill already in flight), from the top down.
                     while (L.sp > 0) {
-                        pass = L.t_min >= __hiloint2double(L.top.y, L.top.x);
-                        if (pass) { L.cur_ref = L.top.z; L.cur_cnt = L.top.w; L.state = LS_IN_JOB; }
-                        --L.sp;
-                        if (L.sp > 0) L.top = stk[L.sp - 1];
-                        if (pass) break;
+                        const v4i e1 = stk[L.sp >= 2 ? L.sp - 2 : 0];
+                        const v4i e2 = stk[L.sp >= 3 ? L.sp - 3 : 0];
+                        const v4i e3 = stk[L.sp >= 4 ? L.sp - 4 : 0];
+                        const bool p0 = L.t_min >= __hiloint2double(L.top.y, L.top.x);
+                        const bool p1 = L.sp >= 2 && L.t_min >= __hiloint2double(e1.y, e1.x);
+                        const bool p2 = L.sp >= 3 && L.t_min >= __hiloint2double(e2.y, e2.x);
+                        const bool p3 = L.sp >= 4 && L.t_min >= __hiloint2double(e3.y, e3.x);
+                        const int k = p0 ? 0 : (p1 ? 1 : (p2 ? 2 : (p3 ? 3 : 4)));     // first that passes; 4: none
+                        if (k < 4) {
+                            L.cur_ref = k == 0 ? L.top.z : (k == 1 ? e1.z : (k == 2 ? e2.z : e3.z));
+                            L.cur_cnt = k == 0 ? L.top.w : (k == 1 ? e1.w : (k == 2 ? e2.w : e3.w));
+                            L.state = LS_IN_JOB;
+                        }
+                        const int used = k < 4 ? k + 1 : 4;
+                        L.sp = L.sp > used ? L.sp - used : 0;
+                        if (L.sp > 0) {                   // the new top: the entry below the last one used
+                            if (k == 0) L.top = e1;
+                            else if (k == 1) L.top = e2;
+                            else if (k == 2) L.top = e3;
+                            else L.top = stk[L.sp - 1];
+                        }
+                        if (k < 4) break;
                     }
                 }
             }
