@@ -27,9 +27,17 @@ $(LIBDIR)/librtx_host.so: $(HOSTSRC)/host_scene.cpp $(HOSTSRC)/json_min.hpp $(HO
 	@mkdir -p $(LIBDIR)
 	$(CXX) $(HOSTFLAGS) -shared -o $@ $(HOSTSRC)/host_scene.cpp
 
-$(LIBDIR)/librtx_amd.so: $(DEVSRC)/rtx_core.hip $(wildcard $(DEVSRC)/*.h) include/rtx_amd.h
+# the BVH builder (rocPRIM templates, slow to compile) is its own object
+$(LIBDIR)/rtx_bvh_build.o: $(DEVSRC)/rtx_bvh_build.hip include/rtx_amd.h
 	@mkdir -p $(LIBDIR)
-	$(HIPCC) $(DEVFLAGS) -shared -o $@ $(DEVSRC)/rtx_core.hip
+	$(HIPCC) $(DEVFLAGS) -c -o $@ $(DEVSRC)/rtx_bvh_build.hip
+
+$(LIBDIR)/rtx_core.o: $(DEVSRC)/rtx_core.hip $(wildcard $(DEVSRC)/*.h) include/rtx_amd.h
+	@mkdir -p $(LIBDIR)
+	$(HIPCC) $(DEVFLAGS) -c -o $@ $(DEVSRC)/rtx_core.hip
+
+$(LIBDIR)/librtx_amd.so: $(LIBDIR)/rtx_core.o $(LIBDIR)/rtx_bvh_build.o
+	$(HIPCC) -shared -fPIC -o $@ $(LIBDIR)/rtx_core.o $(LIBDIR)/rtx_bvh_build.o
 
 $(LIBDIR)/raytracer_amd: $(HOSTSRC)/main.cpp $(LIBDIR)/librtx_host.so $(LIBDIR)/librtx_amd.so
 	$(CXX) $(HOSTFLAGS) -pthread -o $@ $(HOSTSRC)/main.cpp -L$(LIBDIR) -lrtx_host -lrtx_amd \

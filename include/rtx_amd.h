@@ -194,6 +194,18 @@ int rtx_unpack_tiles(const uint8_t* packed, int32_t width, int32_t height,
                      int32_t tile_w, int32_t tile_h, int32_t tile_first, int32_t tile_stride,
                      uint8_t* frame);
 
+/* MeshBVH::build (bvh.cpp:80-102, 187-258) on the device: the reference's tree for one mesh --
+ * same boxes, topology, split axes, pre-order numbering and leaf face sets -- from a
+ * level-synchronous build (segmented reduction + segmented sort per level) instead of the
+ * recursive nth_element build.  Faces inside a leaf come out in sorted order (the reference:
+ * whatever nth_element left), and faces whose centroids tie exactly at a median may change sides.
+ * `faces`: n_faces x 3 indices into `vertices` (3 doubles each); `nodes_out`: room for
+ * 2 * n_faces nodes; `face_indices_out`: n_faces entries; `build_ms` (optional): wall time
+ * including the transfers.  The result goes to rtx_mesh.nodes / face_indices (or to
+ * rtx_host_attach_bvh). */
+int rtx_build_bvh(int32_t device, const double* vertices, int64_t n_vertices, const int32_t* faces, int32_t n_faces,
+                  rtx_bvh_node* nodes_out, int32_t* n_nodes_out, int32_t* face_indices_out, double* build_ms);
+
 /* Collect per-ray work counters in rtx_stats (slower kernels); default off.
  * With counters on, the device carries out every closest-hit query to its end, so that ray
  * and triangle-test counts equal those of the reference's algorithm (utils.cpp:671-865).

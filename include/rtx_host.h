@@ -39,6 +39,14 @@ int rtx_host_load(const char* json_path, int use_bvh, int enable_cull, rtx_host_
  * `prev` is freed, `*out` is the new scene and `*reused = 0`.  On failure `prev` stays valid. */
 int rtx_host_load_next(const char* json_path, rtx_host_scene* prev, rtx_host_scene** out, int* reused);
 
+/* Give mesh `mesh` of a scene loaded with use_bvh = 0 a BVH built elsewhere -- in practice by
+ * rtx_build_bvh (rtx_amd.h), the device-side MeshBVH::build -- in the reference's layout
+ * (bvh.h:50-66).  The arrays are copied; the description's mesh entry points at the copies.
+ * World boxes of transformed objects do not change: the root box the reference takes them from
+ * (scene.cpp:867-879) equals the box over the mesh's vertices used without a BVH. */
+int rtx_host_attach_bvh(rtx_host_scene* scene, int mesh, const rtx_bvh_node* nodes, int n_nodes,
+                        const int32_t* face_indices);
+
 /* The description; valid until rtx_host_free (light array: until the next rtx_host_load_next). */
 const rtx_scene_desc* rtx_host_desc(const rtx_host_scene* scene);
 

@@ -70,6 +70,28 @@ class HostScene:
         self.path = json_path
         return bool(reused.value)
 
+    def build_bvh_on_device(self, device: int = 0) -> float:
+        """For a scene loaded with ``use_bvh=False``: build every mesh's BVH on the GPU
+        (rtx_build_bvh) and attach it.  Returns the total build time in ms."""
+        lib = amd_lib()
+        d = self.desc.contents
+        total = 0.0
+        for i in range(d.n_meshes):
+            m = d.meshes[i]
+            if m.n_faces <= 0:
+                continue
+            nodes = (_abi.BvhNode * (2 * m.n_faces))()
+            order = (C.c_int32 * m.n_faces)()
+            n_nodes, ms = C.c_int32(0), C.c_double(0.0)
+            rc = lib.rtx_build_bvh(device, d.vertices, d.n_vertices, m.faces, m.n_faces, nodes, C.byref(n_nodes), order,
+                                   C.byref(ms))
+            if rc != 0:
+                raise RtxError(f"rtx_build_bvh failed ({rc}): {lib.rtx_last_error().decode()}")
+            if self._lib.rtx_host_attach_bvh(self._h, i, nodes, n_nodes.value, order) != 0:
+                raise RtxError(self._lib.rtx_host_last_error().decode())
+            total += ms.value
+        return total
+
     def lights(self):
         d = self.desc.contents
         return [d.lights[i] for i in range(d.n_lights)]

@@ -110,11 +110,11 @@ HIT_DTYPE = [("kind", "<i4"), ("container", "<i4"), ("face", "<i4"), ("src", "<i
              ("distance", "<f8")]
 
 # Symbols every library must export (checked by the CPU-side ABI test).
-AMD_SYMBOLS = ["rtx_scene_create", "rtx_scene_update_lights", "rtx_render",
+AMD_SYMBOLS = ["rtx_build_bvh", "rtx_scene_create", "rtx_scene_update_lights", "rtx_render",
                "rtx_render_output_bytes", "rtx_unpack_tiles", "rtx_scene_set_counters",
                "rtx_scene_set_queue_limit", "rtx_scene_destroy", "rtx_last_error",
                "rtx_device_count"]
-HOST_SYMBOLS = ["rtx_host_load", "rtx_host_load_next", "rtx_host_desc", "rtx_host_camera_count", "rtx_host_camera",
+HOST_SYMBOLS = ["rtx_host_load", "rtx_host_load_next", "rtx_host_attach_bvh", "rtx_host_desc", "rtx_host_camera_count", "rtx_host_camera",
                 "rtx_host_timings", "rtx_host_dump", "rtx_host_free", "rtx_host_write_ppm",
                 "rtx_host_write_png", "rtx_host_last_error"]
 
@@ -125,6 +125,8 @@ def load_host_lib():
     lib.rtx_host_load.restype = C.c_int
     lib.rtx_host_load_next.argtypes = [C.c_char_p, C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int)]
     lib.rtx_host_load_next.restype = C.c_int
+    lib.rtx_host_attach_bvh.argtypes = [C.c_void_p, C.c_int, C.POINTER(BvhNode), C.c_int, C.POINTER(C.c_int32)]
+    lib.rtx_host_attach_bvh.restype = C.c_int
     lib.rtx_host_desc.argtypes = [C.c_void_p]
     lib.rtx_host_desc.restype = C.POINTER(SceneDesc)
     lib.rtx_host_camera_count.argtypes = [C.c_void_p]
@@ -151,6 +153,9 @@ def load_amd_lib():
     there is no CPU fallback behind this API."""
     # RTX_AMD_LIB selects another build of the same library (kernel experiments).
     lib = C.CDLL(os.environ.get("RTX_AMD_LIB") or os.path.join(LIB_DIR, "librtx_amd.so"))
+    lib.rtx_build_bvh.argtypes = [C.c_int32, C.POINTER(C.c_double), C.c_int64, C.POINTER(C.c_int32), C.c_int32,
+                                  C.POINTER(BvhNode), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_double)]
+    lib.rtx_build_bvh.restype = C.c_int
     lib.rtx_scene_create.argtypes = [C.POINTER(SceneDesc), C.c_int, C.POINTER(C.c_void_p)]
     lib.rtx_scene_create.restype = C.c_int
     lib.rtx_scene_update_lights.argtypes = [C.c_void_p, C.POINTER(Light), C.c_int32]

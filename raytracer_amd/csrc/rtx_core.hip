@@ -527,9 +527,21 @@ HitBuf make_hitbuf(void* base, size_t) {
 
 }  // namespace
 
+// rtx_bvh_build.hip
+namespace rtxbuild {
+void set_error(const std::string& s) { g_error = s; }
+int build(int device, const double* vertices, int64_t n_vertices, const int32_t* faces, int32_t n_faces,
+          rtx_bvh_node* nodes_out, int32_t* n_nodes_out, int32_t* face_indices_out, double* build_ms);
+}  // namespace rtxbuild
+
 extern "C" {
 
 const char* rtx_last_error(void) { return g_error.c_str(); }
+
+int rtx_build_bvh(int32_t device, const double* vertices, int64_t n_vertices, const int32_t* faces, int32_t n_faces,
+                  rtx_bvh_node* nodes_out, int32_t* n_nodes_out, int32_t* face_indices_out, double* build_ms) {
+    return rtxbuild::build(device, vertices, n_vertices, faces, n_faces, nodes_out, n_nodes_out, face_indices_out, build_ms);
+}
 
 int rtx_device_count(void) {
     int n = 0;

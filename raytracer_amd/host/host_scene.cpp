@@ -1019,6 +1019,36 @@ int rtx_host_camera(const rtx_host_scene* s, int index, rtx_camera* out, char* i
     return 0;
 }
 
+int rtx_host_attach_bvh(rtx_host_scene* s, int mesh, const rtx_bvh_node* nodes, int n_nodes, const int32_t* face_indices) {
+    if (!s || mesh < 0 || (size_t)mesh >= s->meshes.size() || n_nodes < 0 || (n_nodes > 0 && (!nodes || !face_indices))) {
+        g_error = "rtx_host_attach_bvh: bad argument";
+        return -1;
+    }
+    HostMesh& m = s->meshes[(size_t)mesh];
+    const size_t nf = m.faces.size() / 3;
+    // the tree must be a well-formed one over this mesh's faces: it will be walked on the device
+    std::vector<char> seen(nf, 0);
+    for (int i = 0; i < n_nodes; i++) {
+        const rtx_bvh_node& n = nodes[i];
+        const bool leaf = n.left < 0;
+        bool ok = leaf ? (n.right < 0 && n.first_face >= 0 && n.face_count >= 0 && (size_t)n.first_face + (size_t)n.face_count <= nf)
+                       : (n.left > i && n.left < n_nodes && n.right > i && n.right < n_nodes);
+        if (!ok) { g_error = "rtx_host_attach_bvh: malformed node " + std::to_string(i); return -1; }
+    }
+    for (size_t i = 0; i < (n_nodes > 0 ? nf : 0); i++) {
+        const int32_t f = face_indices[i];
+        if (f < 0 || (size_t)f >= nf || seen[(size_t)f]) { g_error = "rtx_host_attach_bvh: face_indices is not a permutation of the faces"; return -1; }
+        seen[(size_t)f] = 1;
+    }
+    m.nodes.assign(nodes, nodes + n_nodes);
+    m.face_indices.assign(face_indices, face_indices + (n_nodes > 0 ? nf : 0));
+    rtx_mesh& r = s->mesh_desc[(size_t)mesh];
+    r.nodes = m.nodes.empty() ? nullptr : m.nodes.data();
+    r.n_nodes = (int32_t)m.nodes.size();
+    r.face_indices = m.face_indices.empty() ? nullptr : m.face_indices.data();
+    return 0;
+}
+
 int rtx_host_timings(const rtx_host_scene* s, double* parse_ms, double* preprocess_ms) {
     if (!s) return -1;
     if (parse_ms) *parse_ms = s->parse_ms;

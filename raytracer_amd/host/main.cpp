@@ -2,12 +2,13 @@
 // that renders on the MI355X core instead of the CPU loops.
 //
 //   raytracer_amd <scene.json> [more.json ...] [-b [0|1]] [-m [0|1]] [-c [0|1]]
-//                 [--device D] [--shard R/N] [--out DIR] [--png] [--quiet]
+//                 [--device D] [--shard R/N] [--out DIR] [--png] [--quiet] [--gpu-build]
 //
 // -b  BVH on/off (default on; `-b` alone = on).  Off ships meshes without a BVH; the device
 //     then tests every face of a mesh in face order, like the reference's brute-force loop.
 // -m  accepted for compatibility (the reference's thread switch); it has no effect here.
 // -c  back-face culling (default off; `-c` alone = off, `-c 1` = on), as in the reference.
+// --gpu-build  build the meshes' BVHs on the device (rtx_build_bvh) instead of on the host.
 // --shard R/N  render only scene files i with i % N == R (whole-frame sharding of an
 //     animation across N processes, one per GPU; no communication needed).
 //
@@ -106,7 +107,7 @@ private:
 
 int main(int argc, char** argv) {
     std::vector<std::string> scenes;
-    bool use_bvh = true, cull = false, multithreaded = true, png = false, quiet = false;
+    bool use_bvh = true, cull = false, multithreaded = true, png = false, quiet = false, gpu_build = false;
     int device = 0, shard_r = 0, shard_n = 1;
     std::string out_dir = "../my_outputs_hw2/";            // raytracer.cpp:13
     auto opt01 = [&](int& i, bool bare_value, bool& target) {
@@ -121,11 +122,12 @@ int main(int argc, char** argv) {
         else if (!strcmp(argv[i], "--out") && i + 1 < argc) { out_dir = argv[++i]; if (!out_dir.empty() && out_dir.back() != '/') out_dir += '/'; }
         else if (!strcmp(argv[i], "--shard") && i + 1 < argc) { if (sscanf(argv[++i], "%d/%d", &shard_r, &shard_n) != 2 || shard_n < 1 || shard_r < 0 || shard_r >= shard_n) { fprintf(stderr, "bad --shard\n"); return 2; } }
         else if (!strcmp(argv[i], "--png")) png = true;
+        else if (!strcmp(argv[i], "--gpu-build")) gpu_build = true;
         else if (!strcmp(argv[i], "--quiet")) quiet = true;
         else scenes.push_back(argv[i]);
     }
     if (scenes.empty()) {
-        fprintf(stderr, "usage: raytracer_amd <scene.json>... [-b [0|1]] [-m [0|1]] [-c [0|1]] [--device D] [--shard R/N] [--out DIR] [--png]\n");
+        fprintf(stderr, "usage: raytracer_amd <scene.json>... [-b [0|1]] [-m [0|1]] [-c [0|1]] [--device D] [--shard R/N] [--out DIR] [--png] [--gpu-build]\n");
         return 2;
     }
     (void)multithreaded;
@@ -145,7 +147,7 @@ int main(int argc, char** argv) {
                 continue;                                    // the previous scene stays loaded
             }
             hs = next;
-        } else if (rtx_host_load(scenes[si].c_str(), use_bvh, cull, &hs) != 0) {
+        } else if (rtx_host_load(scenes[si].c_str(), use_bvh && !gpu_build, cull, &hs) != 0) {
             fprintf(stderr, "%s: %s\n", scenes[si].c_str(), rtx_host_last_error());
             rc_all = 1;
             hs = nullptr;
@@ -154,6 +156,28 @@ int main(int argc, char** argv) {
         double parse_ms = 0, pre_ms = 0;
         rtx_host_timings(hs, &parse_ms, &pre_ms);
         const rtx_scene_desc* desc = rtx_host_desc(hs);
+        if (use_bvh && gpu_build && !reused) {
+            // the reference's trees (MeshBVH::build), built on the device and handed to the host scene
+            bool ok = true;
+            for (int m = 0; m < desc->n_meshes && ok; m++) {
+                const rtx_mesh& mesh = desc->meshes[m];
+                if (mesh.n_faces <= 0) continue;
+                std::vector<rtx_bvh_node> nodes(2 * (size_t)mesh.n_faces);
+                std::vector<int32_t> order((size_t)mesh.n_faces);
+                int32_t n_nodes = 0;
+                double ms = 0;
+                if (rtx_build_bvh(device, desc->vertices, desc->n_vertices, mesh.faces, mesh.n_faces, nodes.data(), &n_nodes,
+                                  order.data(), &ms) != RTX_OK) {
+                    fprintf(stderr, "%s: %s\n", scenes[si].c_str(), rtx_last_error());
+                    ok = false;
+                } else if (rtx_host_attach_bvh(hs, m, nodes.data(), n_nodes, order.data()) != 0) {
+                    fprintf(stderr, "%s: %s\n", scenes[si].c_str(), rtx_host_last_error());
+                    ok = false;
+                }
+                pre_ms += ms;
+            }
+            if (!ok) { rc_all = 1; continue; }
+        }
         if (reused && ds) {
             upload_ms = 0;
             if (rtx_scene_update_lights(ds, desc->lights, desc->n_lights) != RTX_OK) {

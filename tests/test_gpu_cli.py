@@ -78,3 +78,18 @@ def test_cli_reports_bad_input(tmp_path):
     r = subprocess.run([CLI, os.path.join(str(tmp_path), "missing.json"), "--out", str(tmp_path)],
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=60)
     assert r.returncode != 0 and "cannot be loaded" in r.stderr
+
+
+def test_gpu_build_flag_gives_the_same_pictures(tmp_path):
+    d = str(tmp_path)
+    frames = [scenes.scene_david_frame(d, f, n_frames=12, faces=5000, res=(96, 80)) for f in range(2)]
+    host_dir, dev_dir = os.path.join(d, "host"), os.path.join(d, "dev")
+    os.makedirs(host_dir); os.makedirs(dev_dir)
+    run_cli(frames + ["--out", host_dir, "--quiet"])
+    out = run_cli(frames + ["--out", dev_dir, "--gpu-build"])
+    assert out.count("geometry kept") == 1
+    for k in range(2):
+        a = read_p3(os.path.join(host_dir, f"davids_camera_{k:03d}.ppm"))
+        b = read_p3(os.path.join(dev_dir, f"davids_camera_{k:03d}.ppm"))
+        same, mx = ck.image_diff(a, b)
+        assert mx <= 1 and same >= 0.999
