@@ -250,7 +250,15 @@ int build(int device, const double* vertices, int64_t n_vertices, const int32_t*
     BUILD_TRY(rocprim::segmented_radix_sort_pairs(nullptr, tmp_sort, d_keys.as<double>(), d_keys_out.as<double>(), d_idx.as<int>(),
                                                   d_sorted.as<int>(), (unsigned)n, (unsigned)max_seg, d_split_begin.as<int>(),
                                                   d_split_end.as<int>(), 0, 64, 0));
-    BUILD_TRY(d_tmp.get(std::max(tmp_reduce, tmp_sort)));
+    // The segmented primitives give one workgroup to a segment; near the root the segments are
+    // few and huge, so levels whose ranges exceed kWide elements use the device-wide primitives,
+    // one call per range.
+    constexpr int kWide = 1 << 15;
+    size_t tmp_wide_reduce = 0, tmp_wide_sort = 0;
+    BUILD_TRY(rocprim::reduce(nullptr, tmp_wide_reduce, in_it, d_red.as<Red>(), red_identity(), (size_t)n, RedOp(), 0));
+    BUILD_TRY(rocprim::radix_sort_pairs(nullptr, tmp_wide_sort, d_keys.as<double>(), d_keys_out.as<double>(), d_idx.as<int>(),
+                                        d_sorted.as<int>(), (size_t)n, 0, 64, 0));
+    BUILD_TRY(d_tmp.get(std::max(std::max(tmp_reduce, tmp_sort), std::max(tmp_wide_reduce, tmp_wide_sort))));
     // ranges of the open nodes of a level, gathered for the reduction
     Buf d_rb, d_re;
     BUILD_TRY(d_rb.get(max_seg * 4));
@@ -258,16 +266,28 @@ int build(int device, const double* vertices, int64_t n_vertices, const int32_t*
 
     std::vector<int> level_first, level_count;
     int n_seg = 1, n_nodes = 1, cur = 0;
-    std::vector<int> h_nodes_of_seg, h_start, h_end;
     for (int depth = 0; n_seg > 0; depth++) {
         level_first.push_back(n_nodes - n_seg);
         level_count.push_back(n_seg);
         // ranges of this level's nodes (they were allocated contiguously: [n_nodes - n_seg, n_nodes))
         BUILD_TRY(hipMemcpy(d_rb.p, d_start.as<int>() + (n_nodes - n_seg), (size_t)n_seg * 4, hipMemcpyDeviceToDevice));
         BUILD_TRY(hipMemcpy(d_re.p, d_end.as<int>() + (n_nodes - n_seg), (size_t)n_seg * 4, hipMemcpyDeviceToDevice));
-        size_t tb = tmp_reduce;
-        BUILD_TRY(rocprim::segmented_reduce(d_tmp.p, tb, in_it, d_red.as<Red>(), (unsigned)n_seg, d_rb.as<int>(), d_re.as<int>(),
-                                            RedOp(), red_identity(), 0));
+        const bool wide = n_seg <= 64 && n / n_seg > kWide;
+        std::vector<int> h_b, h_e;
+        if (wide) {
+            h_b.resize((size_t)n_seg); h_e.resize((size_t)n_seg);
+            BUILD_TRY(hipMemcpy(h_b.data(), d_rb.p, (size_t)n_seg * 4, hipMemcpyDeviceToHost));
+            BUILD_TRY(hipMemcpy(h_e.data(), d_re.p, (size_t)n_seg * 4, hipMemcpyDeviceToHost));
+            for (int s = 0; s < n_seg; s++) {
+                size_t tb = tmp_wide_reduce;
+                BUILD_TRY(rocprim::reduce(d_tmp.p, tb, in_it + h_b[(size_t)s], d_red.as<Red>() + s, red_identity(),
+                                          (size_t)(h_e[(size_t)s] - h_b[(size_t)s]), RedOp(), 0));
+            }
+        } else {
+            size_t tb = tmp_reduce;
+            BUILD_TRY(rocprim::segmented_reduce(d_tmp.p, tb, in_it, d_red.as<Red>(), (unsigned)n_seg, d_rb.as<int>(), d_re.as<int>(),
+                                                RedOp(), red_identity(), 0));
+        }
         BUILD_TRY(hipMemset(d_counters.p, 0, 16));
         hipLaunchKernelGGL(k_decide, dim3(blocks(n_seg)), dim3(T), 0, 0, n_seg, depth, d_seg_node[cur].as<int>(), d_red.as<Red>(), N,
                            n_nodes, d_counters.as<int>(), d_split_begin.as<int>(), d_split_end.as<int>(), d_seg_axis.as<int>(),
@@ -277,10 +297,23 @@ int build(int device, const double* vertices, int64_t n_vertices, const int32_t*
         if (n_split > 0) {
             hipLaunchKernelGGL(k_keys, dim3(blocks(n)), dim3(T), 0, 0, n, d_pos_seg.as<int>(), d_seg_child.as<int>(),
                                d_seg_axis.as<int>(), d_idx.as<int>(), d_cen.as<double>(), d_keys.as<double>());
-            size_t ts = tmp_sort;
-            BUILD_TRY(rocprim::segmented_radix_sort_pairs(d_tmp.p, ts, d_keys.as<double>(), d_keys_out.as<double>(), d_idx.as<int>(),
-                                                          d_sorted.as<int>(), (unsigned)n, (unsigned)n_split, d_split_begin.as<int>(),
-                                                          d_split_end.as<int>(), 0, 64, 0));
+            if (wide) {
+                h_b.resize((size_t)n_split); h_e.resize((size_t)n_split);
+                BUILD_TRY(hipMemcpy(h_b.data(), d_split_begin.p, (size_t)n_split * 4, hipMemcpyDeviceToHost));
+                BUILD_TRY(hipMemcpy(h_e.data(), d_split_end.p, (size_t)n_split * 4, hipMemcpyDeviceToHost));
+                for (int k = 0; k < n_split; k++) {
+                    const int b = h_b[(size_t)k];
+                    size_t ts = tmp_wide_sort;
+                    BUILD_TRY(rocprim::radix_sort_pairs(d_tmp.p, ts, d_keys.as<double>() + b, d_keys_out.as<double>() + b,
+                                                        d_idx.as<int>() + b, d_sorted.as<int>() + b, (size_t)(h_e[(size_t)k] - b),
+                                                        0, 64, 0));
+                }
+            } else {
+                size_t ts = tmp_sort;
+                BUILD_TRY(rocprim::segmented_radix_sort_pairs(d_tmp.p, ts, d_keys.as<double>(), d_keys_out.as<double>(),
+                                                              d_idx.as<int>(), d_sorted.as<int>(), (unsigned)n, (unsigned)n_split,
+                                                              d_split_begin.as<int>(), d_split_end.as<int>(), 0, 64, 0));
+            }
         }
         hipLaunchKernelGGL(k_advance, dim3(blocks(n)), dim3(T), 0, 0, n, d_pos_seg.as<int>(), d_seg_child.as<int>(),
                            d_seg_node[cur].as<int>(), N, d_sorted.as<int>(), d_idx.as<int>());
