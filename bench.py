@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Benchmark of the hot path: one step = one frame of the workload through rtx_render.
 
-Metric (BASELINE.json): Mrays/s and ms/frame.  A ray is one closest-hit query the reference
+Metric: Mrays/s and ms/frame.  A ray is one closest-hit query the reference
 semantics require (one intersect() call, utils.cpp:671, not counting calls whose result
 computePixelColor discards); the per-frame ray count R is taken from the device's own
 counters in an untimed pass and is, by construction and by test, the count the CPU

@@ -12,7 +12,7 @@
  *
  * Every struct is plain C, pointers + counts only.  Field layouts mirror the
  * reference's in-memory records so that a host that already holds a finished
- * `scene::Scene` can point straight into it (see INTEGRATION.md):
+ * `scene::Scene` can point straight into it:
  *   vertices        <- Scene::vertices.data()                 (scene.h:25-27,167)
  *   rtx_bvh_node    <- MeshBVH::nodes.data()  (72-byte BVHNode, bvh.h:50-61)
  *   face_indices    <- MeshBVH::faceIndices.data()            (bvh.h:66)

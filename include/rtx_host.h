@@ -8,7 +8,7 @@
  * (scene.cpp:827-990, utils.cpp:1184-1361) and per-mesh vertex normals
  * (precompute.cpp:9-44) -- laid out as an `rtx_scene_desc`.  A host that keeps the
  * reference's own loader does not need this library: it fills `rtx_scene_desc` from its
- * `scene::Scene` directly (INTEGRATION.md).
+ * `scene::Scene` directly.
  *
  * All functions return 0 on success, negative on failure (rtx_host_last_error()).
  */
