@@ -851,12 +851,30 @@ RTX_DEV void service_lane(const Launch* __restrict__ Lp, const int gen, double* 
         L.state = LS_NEED_JOB;
         if (COUNT) { const long long c = clock64(); tl.sec[1] += (unsigned long long)(c - c0); tl.sec[5]++; c0 = c; }
     }
-    // A shadow ray with an accepted hit in front of its light is decided (see job_next).  It is
-    // retired here only while its instance candidates have not been collected yet: the lane's
-    // candidate bitmap must be clear when the next ray starts.
+    // A shadow ray with an accepted hit in front of its light is decided (see job_next) and is
+    // retired here.  Instance candidates it has collected but not replayed are dropped: the
+    // lane's candidate bitmap must be clear when the next ray starts.
     double light_dist = 0.0;
     if (!COUNT && L.is_shadow) light_dist = ((const RTX_GLOBAL Ray*)qin.rays + slot)->aux;
-    const bool decided = !COUNT && L.is_shadow && L.hit != 0 && L.t_min < light_dist && L.it <= S.n_meshes;
+    const bool decided = !COUNT && L.is_shadow && L.hit != 0 && L.t_min < light_dist;
+    if (decided && L.it > S.n_meshes) {
+        // (the current word was cleared when it was taken; what is still set in memory: the
+        // words flagged in the current summary word, and the summary words not yet taken)
+        const unsigned n_summary = rtx_summary_words(S.n_insts);
+        unsigned sb = L.sbits;
+        int sw = L.sword;
+        while (true) {
+            while (sb != 0u) {
+                const int w = sw * 32 + (__ffs((int)sb) - 1);
+                sb &= sb - 1u;
+                __hip_atomic_store(inst_bits + n_summary + w, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (sw >= L.whi) break;
+            sw++;
+            sb = atomicExch(inst_bits + sw, 0u);
+        }
+        L.bits = 0u; L.sbits = 0u; L.sword = L.whi;
+    }
     const bool more = !decided && job_next<COUNT>(S, L, out, inst_bits, light_dist, tl);
     if (COUNT) { const long long c = clock64(); tl.sec[2] += (unsigned long long)(c - c0); tl.sec[6]++; c0 = c; }
     if (more) { L.state = LS_IN_JOB; return; }
