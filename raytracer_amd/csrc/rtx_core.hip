@@ -826,6 +826,8 @@ int rtx_render(rtx_scene* sc, const rtx_camera* cam, int32_t tw, int32_t th, int
                 fprintf(stderr, "[rtx] gen %d: %llu rays, %llu wave-steps, %llu service passes; longest wave %.1f us "
                         "(at 2.4 GHz): %llu steps, %llu service passes\n", gen, c.rays, c.inner_steps + c.leaf_steps,
                         c.service_passes, (double)c.max_wave_ticks / 2400.0, c.max_wave_steps & 0xFFFFFFFFull, c.max_wave_steps >> 32);
+                fprintf(stderr, "[rtx]        longest ray: %llu steps, %s, local pixel %llu\n", c.longest_ray >> 32,
+                        (c.longest_ray & 0x80000000ull) ? "shadow" : "radiance", c.longest_ray & 0x7FFFFFFFull);
                 const double nst = (double)std::max(1ull, c.inner_steps + c.leaf_steps);
                 fprintf(stderr, "[rtx]        ticks per wave-step: %.0f (fetch %.0f, pop %.0f); per service pass: %.0f; "
                         "mean wave lifetime %.1f us (traversing %.1f, servicing %.1f)\n",

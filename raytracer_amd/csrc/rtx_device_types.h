@@ -208,6 +208,7 @@ struct Counters {
     unsigned long long section[8];   // service sections: ticks summed over lanes (begin, finalize, next job, complete), then call counts
     unsigned long long ray_steps_hist[8];   // rays by traversal steps: < 16, < 32, ..., < 1024, >= 1024
     unsigned long long shadow_steps_hist[8]; // the shadow rays among them
+    unsigned long long longest_ray;          // (steps << 32) | pixel of the ray with the most traversal steps (atomic max)
 };
 
 }  // namespace rtxdev

@@ -187,7 +187,7 @@ struct Tally { unsigned node_visits, tri_tests, world_box, obj_trav, tlas_visits
                unsigned passes;                                                  // service passes (lane 0)
                unsigned long long clk_trav, clk_serv, clk_total, clk_fetch, clk_pop;
                unsigned long long sec[8];
-               unsigned hist[8], hist_shadow[8]; };   // per-lane section profile of service_lane: ticks (0-3), calls (4-7)              // shader-clock ticks (lane 0)
+               unsigned hist[8], hist_shadow[8]; unsigned long long longest_ray; };   // per-lane section profile of service_lane: ticks (0-3), calls (4-7)              // shader-clock ticks (lane 0)
 
 #define RTX_STACK 100                // BLAS traversal stack entries per lane (BVH depth <= 64)
 #define RTX_TLAS_STACK 48
@@ -912,6 +912,11 @@ RTX_DEV void service_lane(const Launch* __restrict__ Lp, const int gen, double* 
         for (int a = L.age >> 4; a > 0 && b < 7; a >>= 1) b++;
         tl.hist[b]++;
         if (L.is_shadow) tl.hist_shadow[b]++;
+        unsigned pix = slot;
+        if (gen != 0) pix = ((const RTX_GLOBAL Ray*)qin.rays + slot)->pixel;
+        const unsigned long long packed = ((unsigned long long)(unsigned)L.age << 32) | (unsigned long long)(pix & 0x7FFFFFFFu) |
+                                          (L.is_shadow ? 0x80000000ull : 0ull);
+        if (packed > tl.longest_ray) tl.longest_ray = packed;
     }
 }
 
@@ -1248,6 +1253,11 @@ k_trace(const Launch* __restrict__ Lp, GenCtrl* ctrl, const int gen, double* __r
             unsigned long long x = v[k];
             for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off);
             if (lane == 0 && x) atomicAdd(((unsigned long long*)counters) + k, x);
+        }
+        {
+            unsigned long long x = tl.longest_ray;
+            for (int off = 32; off > 0; off >>= 1) { const unsigned long long y = __shfl_down(x, off); x = y > x ? y : x; }
+            if (lane == 0 && x) atomicMax(&counters->longest_ray, x);
         }
         if (lane == 0) {
             const unsigned long long life = (unsigned long long)(clock64() - clk_begin);
