@@ -1,0 +1,108 @@
+"""Edge cases of the hot path on the GPU, each checked against the CPU oracle: empty and
+degenerate inputs, image sizes that do not fill a wave or an 8x8 block, recursion depth 0,
+meshes without faces and instances of them, scenes without lights, many tiny tiles."""
+import numpy as np
+import pytest
+
+import _checkers as ck
+import raytracer_amd as rt
+from raytracer_amd import scenes
+from raytracer_amd.scenes import _camera, _dump, _flat, _light, _mat
+
+pytestmark = pytest.mark.gpu
+
+GROUND = [(-6, 0, 6), (6, 0, 6), (6, 0, -6), (-6, 0, -6)]
+PYRAMID = [(-1, 0, 1), (1, 0, 1), (1, 0, -1), (-1, 0, -1), (0, 1.6, 0)]
+
+
+def base_scene(res, depth=3, lights=True, name="edge.png"):
+    return {
+        "BackgroundColor": "7 11 13", "MaxRecursionDepth": str(depth), "ShadowRayEpsilon": "1e-3",
+        "IntersectionTestEpsilon": "1e-6",
+        "Cameras": {"Camera": _camera((0.3, 2.5, 7), (0, 0.6, 0), (0, 1, 0), 40, res, name)},
+        "Lights": {"AmbientLight": "30 30 30",
+                   **({"PointLight": [_light(1, (4, 6, 5), (9000, 9000, 9000)), _light(2, (-5, 3, 2), (4000, 3000, 2000))]}
+                      if lights else {})},
+        "Materials": {"Material": [
+            _mat(1, (1, 1, 1), (0.6, 0.6, 0.6), (0.2, 0.2, 0.2), phong=8, mirror=(0.5, 0.5, 0.5)),
+            _mat(2, (1, 0.5, 0.5), (0.7, 0.3, 0.3), (0.4, 0.4, 0.4), phong=20)]},
+        "VertexData": {"_data": _flat(np.array(GROUND + PYRAMID, dtype=np.float64))},
+    }
+
+
+def check(path, cull=False):
+    hs = rt.HostScene(path, True, cull)
+    ds = rt.DeviceScene(hs.desc, 0)
+    out = []
+    for counters in (True, False):
+        ds.set_counters(counters)
+        for k in range(hs.n_cameras):
+            cam, _ = hs.camera(k)
+            rgb, hits, st = ds.render(cam, want_hits=True)
+            o_rgb, o_hits, o_ctr, _ = ck.oracle_render(hs.desc, cam)
+            assert len(ck.compare_hits(hits, o_hits, allow_src_unknown=False)) == 0
+            same, mx = ck.image_diff(rgb, o_rgb)
+            assert mx <= 2 and same >= 0.999, (same, mx)
+            if counters:
+                assert st["rays"] == o_ctr["rays"] and st["tri_tests"] == o_ctr["tri_tests"]
+            out.append((rgb, hits))
+    ds.close(); hs.close()
+    return out
+
+
+def test_scene_without_objects(tmp_path):
+    sc = base_scene((7, 5))
+    path = _dump(str(tmp_path / "empty.json"), sc)
+    (rgb, hits), _ = check(path)
+    assert np.all(rgb.reshape(-1, 3) == np.array([7, 11, 13], dtype=np.uint8)) and np.all(hits["kind"] == 0)
+
+
+@pytest.mark.parametrize("res", [(1, 1), (13, 7), (65, 3), (8, 8), (9, 64)])
+def test_image_sizes_off_the_block_grid(tmp_path, res):
+    sc = base_scene(res)
+    sc["Objects"] = {"Mesh": [{"_id": "1", "Material": "1", "Faces": {"_data": "1 2 3 1 3 4"}},
+                              {"_id": "2", "Material": "2", "Faces": {"_data": "5 6 9 6 7 9 7 8 9 8 5 9"}}]}
+    check(_dump(str(tmp_path / "odd.json"), sc))
+
+
+def test_recursion_depth_zero_and_no_lights(tmp_path):
+    sc = base_scene((40, 30), depth=0)
+    sc["Objects"] = {"Mesh": [{"_id": "1", "Material": "1", "Faces": {"_data": "1 2 3 1 3 4"}},
+                              {"_id": "2", "Material": "2", "Faces": {"_data": "5 6 9 6 7 9 7 8 9 8 5 9"}}]}
+    check(_dump(str(tmp_path / "d0.json"), sc))
+    sc2 = base_scene((40, 30), depth=2, lights=False)
+    sc2["Objects"] = sc["Objects"]
+    check(_dump(str(tmp_path / "nolights.json"), sc2))
+
+
+def test_meshes_without_faces_and_instances_of_them(tmp_path):
+    sc = base_scene((48, 36))
+    sc["Transformations"] = {"Translation": [{"_id": "1", "_data": "2.5 0 0"}, {"_id": "2", "_data": "-2.5 0 -1"}],
+                             "Scaling": [{"_id": "1", "_data": "0.5 2 0.5"}]}
+    sc["Objects"] = {
+        "Mesh": [{"_id": "1", "Material": "1", "Faces": {"_data": "1 2 3 1 3 4"}},
+                 {"_id": "2", "Material": "2", "Faces": {"_data": ""}},                       # no faces at all
+                 {"_id": "3", "Material": "2", "Faces": {"_data": "5 6 9 6 7 9 7 8 9 8 5 9"}}],
+        "MeshInstance": [{"_id": "4", "_baseMeshId": "2", "Material": "1", "Transformations": "t1"},        # of the empty mesh
+                         {"_id": "5", "_baseMeshId": "3", "Material": "1", "Transformations": "s1 t1"},
+                         {"_id": "6", "_baseMeshId": "77", "Transformations": "t2"},                        # unresolved base
+                         {"_id": "7", "_baseMeshId": "5", "_resetTransform": "false", "Transformations": "t2"}]}
+    check(_dump(str(tmp_path / "emptymesh.json"), sc))
+    check(_dump(str(tmp_path / "emptymesh.json"), sc), cull=True)
+
+
+def test_many_tiny_tiles(tmp_path):
+    path = scenes.scene_tiny(str(tmp_path), res=(37, 29))
+    hs = rt.HostScene(path)
+    ds = rt.DeviceScene(hs.desc, 0)
+    cam, _ = hs.camera(0)
+    full, _, _ = ds.render(cam)
+    for tile, world in (((1, 1), 3), ((5, 3), 7), ((64, 64), 2), ((37, 1), 29)):
+        frame = np.zeros_like(full)
+        for rank in range(world):
+            packed, _ = ds.render_tiles(cam, tile[0], tile[1], rank, world)
+            if packed.size:
+                rt.unpack_tiles(packed, cam.width, cam.height, tile[0], tile[1], rank, world, frame)
+        same, mx = ck.image_diff(frame, full)
+        assert mx <= 1 and same >= 0.995, (tile, world, same, mx)
+    ds.close(); hs.close()
