@@ -426,6 +426,9 @@ enum { LS_EMPTY = 0, LS_NEED_JOB = 1, LS_JOB_DONE = 2, LS_IN_JOB = 3 };
 
 #define RTX_SERVICE_THRESHOLD 24     // lanes waiting for service that trigger a service pass ...
 #define RTX_SERVICE_THRESHOLD_INSTANCED 36   // ... and in scenes where a pass replays many instance candidates
+#ifndef RTX_SERVICE_REPS
+#define RTX_SERVICE_REPS 4           // rounds of a service pass: lanes whose ray ended in one round are refilled in the next
+#endif
 #define RTX_SPARSE_LANES 2           // at most this many traversing lanes: load records directly
 #define RTX_CHUNK 256                // rays a wave claims per atomic
 #ifndef RTX_TRACE_WAVES
@@ -1182,7 +1185,7 @@ k_trace(const Launch* __restrict__ Lp, GenCtrl* ctrl, const int gen, double* __r
         if (n_service > 0 && (m_trav == 0ull || n_service >= service_threshold)) {
             // ---- service pass ---------------------------------------------------------------
             const long long c0 = COUNT ? clock64() : 0;
-            for (int rep = 0; rep < 4; rep++) {
+            for (int rep = 0; rep < RTX_SERVICE_REPS; rep++) {
                 const unsigned long long me_ = __ballot(L.state == LS_EMPTY);
                 bool fresh = false;
                 if (me_ != 0ull && !drained) {
