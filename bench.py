@@ -410,6 +410,10 @@ def main():
                          "algorithmic_bytes_per_frame": alg_bytes_rank,
                          "algorithmic_bytes_per_ray": alg_bytes_rank / max(rays_rank, 1),
                          "algorithmic_source": alg_source, "counters_agree": counters_agree,
+                         "note": ("algorithmic bytes are those of the reference's algorithm (its work counts x its record "
+                                  "sizes); the device may undercut them with result-identical shortcuts (TLAS instead of the "
+                                  "linear instance loop, early retirement of occluded shadow rays, caches), so on workloads "
+                                  "where the reference re-reads a small working set per ray frac can exceed 1"),
                          "reference_work_counts": ref_counts,
                          "device_record_visits": int(cst["node_visits"]), "tri_tests": int(cst["tri_tests"]),
                          "device_world_box_tests": int(cst["world_box_tests"]),
