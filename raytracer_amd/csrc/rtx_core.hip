@@ -74,6 +74,7 @@ struct rtx_scene {
     DevBuf materials, lights, xforms, planes, spheres, ftris, meshes, insts, objs, blas, tri_vn;
     DevBuf accum, rgb, aov, ctrl, counters, queue[2], hitbuf, launch, stacks, inst_bits;
     size_t inst_bits_cleared = 0;   // bytes of inst_bits known to be all zero
+    int record_levels = 0;          // deepest chain of records in any BLAS or the TLAS
     ~rtx_scene() {
         for (hipEvent_t e : gen_events) (void)hipEventDestroy(e);
         if (ev0) (void)hipEventDestroy(ev0);
@@ -91,6 +92,7 @@ struct Flat {
     std::vector<double> tri_vn;         // RTX_VN_STRIDE doubles per triangle
     std::vector<Mesh> meshes;
     bool any_vn = false;
+    int record_levels = 0;              // deepest chain of records (collapsed nodes + leaf) in any tree
 };
 
 int push_tri(const rtx_scene_desc& d, const rtx_mesh& m, int face, Flat& F) {
@@ -176,6 +178,7 @@ int flatten_mesh(const rtx_scene_desc& d, const rtx_mesh& m, Flat& F) {
             if (m.nodes[i].left != -1) { st.emplace_back(m.nodes[i].left, dep + 1); st.emplace_back(m.nodes[i].right, dep + 1); }
         }
         if (3 * ((max_depth + 1) / 2) > RTX_STACK - 2) return fail(RTX_ELIMIT, "BVH deeper than the traversal stack");
+        F.record_levels = std::max(F.record_levels, (max_depth + 1) / 2 + 1);
     }
     // collapse two binary levels per record, records in DFS pre-order
     struct Collapse {
@@ -295,7 +298,9 @@ struct TlasBuild {
         if (hi - lo == 1) slot(o, s, items[(size_t)lo].box, items[(size_t)lo].idx, -2);
         else { const int32_t child = make(lo, hi, level + 1); slot(o, s, range_box(lo, hi), child, 0); }
     }
+    int max_level = 0;
     int32_t make(int lo, int hi, int level = 0) {       // record for items [lo, hi), at least one
+        max_level = std::max(max_level, level);
         const int32_t id = (int32_t)nodes.size();
         nodes.emplace_back();
         Node4 o;
@@ -440,6 +445,7 @@ int build_scene(rtx_scene& sc, const rtx_scene_desc& d) {
         const HBox all = tb.range_box(0, (int)items.size());
         memcpy(S.tl_min, all.mn, 24); memcpy(S.tl_max, all.mx, 24);
         tlas_root = tb.make(0, (int)items.size());
+        F.record_levels = std::max(F.record_levels, tb.max_level + 1);
         S.n_insts = d.n_instances;
     }
     // record indices -> keys (offsets in 128-byte units into the joint node + triangle allocation)
@@ -451,6 +457,7 @@ int build_scene(rtx_scene& sc, const rtx_scene_desc& d) {
     S.tri_key0 = tri_key0;
 
     S.tl_key = tlas_root >= 0 ? 2 * tlas_root : 0;
+    sc.record_levels = F.record_levels;
 
     // per-object records: meshes first, then instances
     std::vector<Obj> objs((size_t)d.n_meshes + (size_t)d.n_instances);
@@ -723,6 +730,9 @@ int rtx_render(rtx_scene* sc, const rtx_camera* cam, int32_t tw, int32_t th, int
         // that long (a chain of dependent loads per candidate), so scenes with many instances
         // gather more lanes per pass.
         launch.service_threshold = sc->dev.n_insts >= 256 ? RTX_SERVICE_THRESHOLD_INSTANCED : RTX_SERVICE_THRESHOLD;
+        // wave-wide traversal of a drained generation's last jobs: its visiting-order keys hold 26 record levels
+        launch.wide_ok = (sc->record_levels <= 26 && !getenv("RTX_AMD_NO_WIDE")) ? 1u : 0u;
+        launch.pad_launch = 0;
         HIP_TRY(sc->launch.ensure(sizeof(Launch)));
         // pageable source: the copy is staged before the call returns, so `launch` may go out of scope
         HIP_TRY(hipMemcpyAsync(sc->launch.p, &launch, sizeof launch, hipMemcpyHostToDevice, sc->stream));
@@ -747,12 +757,16 @@ int rtx_render(rtx_scene* sc, const rtx_camera* cam, int32_t tw, int32_t th, int
             if (gen == 0) blocks = (unsigned)std::min<int64_t>(persistent_blocks, (n_items0 + 255) / 256);
             rtx_hit_id* aov = (gen == 0 && hit_ids) ? (rtx_hit_id*)sc->aov.p : nullptr;
             if (sc->counters_on)
-                hipLaunchKernelGGL(k_trace<true>, dim3(blocks), dim3(256), 0, sc->stream, lp, (GenCtrl*)sc->ctrl.p, gen,
+                hipLaunchKernelGGL((k_trace<true, false>), dim3(blocks), dim3(256), 0, sc->stream, lp, (GenCtrl*)sc->ctrl.p, gen,
                                    (double*)sc->accum.p, aov, (Counters*)sc->counters.p + gen);
             else
-                hipLaunchKernelGGL(k_trace<false>, dim3(blocks), dim3(256), 0, sc->stream, lp, (GenCtrl*)sc->ctrl.p, gen,
+                hipLaunchKernelGGL((k_trace<false, false>), dim3(blocks), dim3(256), 0, sc->stream, lp, (GenCtrl*)sc->ctrl.p, gen,
                                    (double*)sc->accum.p, aov, (Counters*)nullptr);
             HIP_TRY(hipEventRecord(gev[2 * gen + 1], sc->stream));
+            // the variant for tiny generations (one of the two returns at once; see k_trace)
+            if (!sc->counters_on && launch.wide_ok)
+                hipLaunchKernelGGL((k_trace<false, true>), dim3(blocks), dim3(256), 0, sc->stream, lp, (GenCtrl*)sc->ctrl.p, gen,
+                                   (double*)sc->accum.p, aov, (Counters*)nullptr);
             // the last generation holds shadow rays only: nothing left to shade
             if (gen + 1 < G)
                 hipLaunchKernelGGL(k_shade, dim3(blocks), dim3(256), 0, sc->stream, lp, (GenCtrl*)sc->ctrl.p, gen,
@@ -783,7 +797,7 @@ int rtx_render(rtx_scene* sc, const rtx_camera* cam, int32_t tw, int32_t th, int
                 (void)hipEventElapsedTime(&t_shade, gev[2 * gen + 1], gev[2 * gen + 2]);
                 unsigned long long c = (unsigned long long)n_items0;
                 if (gen > 0) { c = 0; for (const SubCount& sub : ctrl[gen].sub) c += sub.counts; }
-                fprintf(stderr, "[rtx] gen %d: radiance %u shadow %u trace %.1f us shade(+resolve) %.1f us\n", gen,
+                fprintf(stderr, "[rtx] gen %d: radiance %u shadow %u trace %.1f us tiny-generation trace + shade (+resolve) %.1f us\n", gen,
                         (unsigned)c, (unsigned)(c >> 32), t_trace * 1e3, t_shade * 1e3);
             }
         }

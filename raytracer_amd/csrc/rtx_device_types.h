@@ -196,6 +196,8 @@ struct Launch {
     uint32_t inst_words;
     // Lanes waiting for service that make a wave of the trace kernel leave its traversal loop.
     uint32_t service_threshold;
+    // The records are shallow enough (<= 26 levels) for the wave-wide traversal's visiting-order keys.
+    uint32_t wide_ok, pad_launch;
 };
 
 struct Counters {

@@ -954,8 +954,225 @@ RTX_DEV void cand_swap(Cand& a, Cand& b, bool doit) {
     b.e = doit ? x.e : y.e; b.ref = doit ? x.ref : y.ref; b.cnt = doit ? x.cnt : y.cnt; b.ok = doit ? x.ok : y.ok;
 }
 
-template <bool COUNT>
-RTX_DEV void traverse_steps(const Scene& S, const Wave& wv, Lane& L, glob_v4i* __restrict__ stk, unsigned* inst_bits,
+// ---- one lane's job, traversed by the whole wave ------------------------------------------
+//
+// When a generation has drained, what is left of it is a handful of long rays, each a chain of
+// several hundred dependent steps in an otherwise idle wave; the kernel's duration is that
+// chain.  Here the wave's 64 lanes work through the *frontier* of one such job instead: every
+// lane takes one open node, tests it, and puts the children that pass back (a LIFO frontier in
+// the wave's LDS rows, so the order stays close to depth-first and the bound tightens early).
+//
+// The result is the reference's.  bvh.cpp:104-185 returns the triangle with the smallest t
+// below the incoming bound, ties going to the one it visits first (strict `t < t_min`).  A node
+// is skipped only if its entry distance exceeds the current bound -- then every hit inside is
+// farther than a hit already found -- so visiting *more* nodes than the reference cannot change
+// the minimum, and ties are decided by the visiting order itself, carried along as a key: the
+// rank of the frontier entry the path started from (the current node, then the stack from the
+// top), then two bits per record level = the child's position in the reference's near-to-far
+// order; within a leaf the triangle's position.  Every triangle is tested against the incoming
+// bound and the minimum of (t, key, triangle) is taken at the end.
+#define RTX_WIDE_LANES 6             // at most this many unfinished jobs in a drained wave: run them wave-wide
+#ifndef RTX_WIDE_MAX_RAYS
+#define RTX_WIDE_MAX_RAYS 512        // generations with at most this many rays use it
+#endif
+#define RTX_WIDE_CAP 480             // frontier entries (32 bytes) in the wave's LDS rows
+#define RTX_WIDE_KEY_SHIFT 52        // first record level's two key bits; ten bits above them for the starting rank
+
+RTX_DEV double bcast_d(double v, int src) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), src), __builtin_amdgcn_readlane(__double2loint(v), src));
+}
+RTX_DEV double wave_min_d(double v) {
+    for (int off = 32; off > 0; off >>= 1) { const double o = __shfl_xor(v, off); v = o < v ? o : v; }
+    return v;
+}
+RTX_DEV unsigned long long wave_min_u64(unsigned long long v) {
+    for (int off = 32; off > 0; off >>= 1) { const unsigned long long o = __shfl_xor(v, off); v = o < v ? o : v; }
+    return v;
+}
+RTX_DEV int wave_min_i(int v) {
+    for (int off = 32; off > 0; off >>= 1) { const int o = __shfl_xor(v, off); v = o < v ? o : v; }
+    return v;
+}
+RTX_DEV int wave_max_i(int v) {
+    for (int off = 32; off > 0; off >>= 1) { const int o = __shfl_xor(v, off); v = o > v ? o : v; }
+    return v;
+}
+
+RTX_DEV void wide_job(const Scene& S, const Wave& wv, Lane& L, glob_v4i* stk, unsigned* inst_bits, const unsigned inst_words,
+                      const int src) {
+    const unsigned lane = wv.lane;
+    const char* const blas = S.blas;
+    const unsigned n_summary = rtx_summary_words(S.n_insts);
+    // the owner's job, wave-uniform
+    Slab sl;
+    sl.ox = bcast_d(L.ro.x, src); sl.oy = bcast_d(L.ro.y, src); sl.oz = bcast_d(L.ro.z, src);
+    sl.ix = bcast_d(L.ix, src); sl.iy = bcast_d(L.iy, src); sl.iz = bcast_d(L.iz, src);
+    sl.par = __builtin_amdgcn_readlane(L.par, src);
+    const V3 ro = mk(sl.ox, sl.oy, sl.oz);
+    const V3 rd = mk(bcast_d(L.rd.x, src), bcast_d(L.rd.y, src), bcast_d(L.rd.z, src));
+    const double b_init = bcast_d(L.t_min, src);
+    const double stop = bcast_d(L.orig_t_min, src);
+    const bool any_hit = (__builtin_amdgcn_readlane(L.is_shadow, src) & 2) != 0;
+    const int o_sp = __builtin_amdgcn_readlane(L.sp, src);
+    const int delta = src - (int)lane;
+    const glob_v4i* o_stk = stk + (long)delta * RTX_STACK;
+    unsigned* o_bits = inst_bits + (long)delta * (long)inst_words;
+    const bool cull = S.cull != 0;
+    const double isect_eps = S.isect_eps;
+
+    // frontier: entry i = two 16-byte halves {enter, ref, cnt} {key, shift, -}; the owner's stack from
+    // the bottom, its register-held top, and on top of everything the node it is at
+    lds_v4i* F = (lds_v4i*)wv.rows;
+    __builtin_amdgcn_wave_barrier();
+    for (int base = 0; base < o_sp - 1; base += 64) {
+        const int i = base + (int)lane;
+        if (i < o_sp - 1) {
+            const v4i e = o_stk[i];
+            const unsigned long long key = (unsigned long long)(unsigned)(o_sp - i) << (RTX_WIDE_KEY_SHIFT + 2);
+            v4i k; k.x = (int)(unsigned)key; k.y = (int)(unsigned)(key >> 32); k.z = RTX_WIDE_KEY_SHIFT; k.w = 0;
+            F[2 * i] = e; F[2 * i + 1] = k;
+        }
+    }
+    {
+        v4i t;
+        t.x = __builtin_amdgcn_readlane(L.top.x, src); t.y = __builtin_amdgcn_readlane(L.top.y, src);
+        t.z = __builtin_amdgcn_readlane(L.top.z, src); t.w = __builtin_amdgcn_readlane(L.top.w, src);
+        v4i c;
+        c.x = __double2loint(-DBL_MAX); c.y = __double2hiint(-DBL_MAX);
+        c.z = __builtin_amdgcn_readlane(L.cur_ref, src); c.w = __builtin_amdgcn_readlane(L.cur_cnt, src);
+        if (lane == 0) {
+            v4i k; k.z = RTX_WIDE_KEY_SHIFT; k.w = 0;
+            if (o_sp > 0) {
+                const unsigned long long key = 1ull << (RTX_WIDE_KEY_SHIFT + 2);
+                k.x = (int)(unsigned)key; k.y = (int)(unsigned)(key >> 32);
+                F[2 * (o_sp - 1)] = t; F[2 * (o_sp - 1) + 1] = k;
+            }
+            k.x = 0; k.y = 0;
+            F[2 * o_sp] = c; F[2 * o_sp + 1] = k;
+        }
+    }
+    int count = o_sp + 1;
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_wave_barrier();
+
+    double B = b_init;                                   // current bound, identical in all lanes
+    double best_t = INFINITY;
+    unsigned long long best_key = ~0ull;
+    int best_tri = INT_MAX;
+    int wmin = INT_MAX, wmax = -1;
+    while (count > 0) {
+        int W = (RTX_WIDE_CAP - 104 - count) / 4;        // room for four pushes per lane, and for a depth-first descent when it is tight
+        W = W > 64 ? 64 : (W < 1 ? 1 : W);
+        W = W > count ? count : W;
+        const bool active = (int)lane < W;
+        const int idx = count - 1 - (int)lane;
+        count -= W;
+        v4i ea = (v4i)(0), eb = (v4i)(0);
+        if (active) { ea = F[2 * idx]; eb = F[2 * idx + 1]; }
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        __builtin_amdgcn_wave_barrier();
+        const bool go = active && B >= __hiloint2double(ea.y, ea.x);
+        const int ref = ea.z, cnt = ea.w;
+        const unsigned long long key = ((unsigned long long)(unsigned)eb.y << 32) | (unsigned)eb.x;
+        const int shift = eb.z;
+        double rec[32];
+        if (go) {
+            const RTX_GLOBAL v2d* gp = (const RTX_GLOBAL v2d*)(blas + ((size_t)(unsigned)ref << 7));
+#pragma unroll
+            for (int p = 0; p < 16; p++) { const v2d v = gp[p]; rec[2 * p] = v.x; rec[2 * p + 1] = v.y; }
+        }
+        // what this lane puts back: up to four entries, farthest first
+        double pe[4]; int pr[4], pc[4], prank[4];
+        int npush = 0;
+        if (go && cnt == 0) {
+            Cand c[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                c[k].ref = k & 1 ? __double2hiint(rec[24 + (k >> 1)]) : __double2loint(rec[24 + (k >> 1)]);
+                c[k].cnt = k & 1 ? __double2hiint(rec[26 + (k >> 1)]) : __double2loint(rec[26 + (k >> 1)]);
+                double e;
+                const bool hit = box_enter(rec + 6 * k, rec + 6 * k + 3, sl, e);
+                c[k].e = e;
+                const bool pass = hit & (B >= e);
+                c[k].ok = pass & (c[k].cnt >= 0);
+                if (pass && c[k].cnt == -2) {            // TLAS walk: candidate instance
+                    const int w = c[k].ref >> 5;
+                    atomicOr(o_bits + n_summary + w, 1u << (c[k].ref & 31));
+                    atomicOr(o_bits + (w >> 5), 1u << (w & 31));
+                    wmin = min(wmin, w); wmax = max(wmax, w);
+                }
+            }
+            const int axis0 = __double2loint(rec[28]), axisL = __double2hiint(rec[28]), axisR = __double2loint(rec[29]);
+            const double d0 = axis0 == 0 ? rd.x : (axis0 == 1 ? rd.y : rd.z);
+            const double dl = axisL == 0 ? rd.x : (axisL == 1 ? rd.y : rd.z);
+            const double dr = axisR == 0 ? rd.x : (axisR == 1 ? rd.y : rd.z);
+            cand_swap(c[0], c[1], !(dl >= 0.0) && c[1].cnt >= 0);
+            cand_swap(c[2], c[3], !(dr >= 0.0) && c[3].cnt >= 0);
+            const bool right_first = !(d0 >= 0.0);
+            cand_swap(c[0], c[2], right_first);
+            cand_swap(c[1], c[3], right_first);
+#pragma unroll
+            for (int k = 3; k >= 0; k--) {
+                if (c[k].ok) { pe[npush] = c[k].e; pr[npush] = c[k].ref; pc[npush] = c[k].cnt; prank[npush] = k; npush++; }
+            }
+        } else if (go && cnt > 0) {
+            const double* td = rec;
+            const double* tq = rec + 16;
+            const bool two = cnt >= 2;
+            bool culled0 = false, culled1 = false;
+            if (cull) {
+                culled0 = rd.x * td[10] + rd.y * td[11] + rd.z * td[12] > 0.0;
+                culled1 = rd.x * tq[10] + rd.y * tq[11] + rd.z * tq[12] > 0.0;
+            }
+            double t, b, g2;
+            if (!culled0 && tri_test(td, ro, rd, b_init, isect_eps, t, b, g2)) {
+                if (t < best_t || (t == best_t && (key < best_key || (key == best_key && ref < best_tri)))) { best_t = t; best_key = key; best_tri = ref; }
+            }
+            if (two && !culled1 && tri_test(tq, ro, rd, b_init, isect_eps, t, b, g2)) {
+                if (t < best_t || (t == best_t && (key < best_key || (key == best_key && ref + 1 < best_tri)))) { best_t = t; best_key = key; best_tri = ref + 1; }
+            }
+            if (cnt > 2) { pe[0] = __hiloint2double(ea.y, ea.x); pr[0] = ref + 2; pc[0] = cnt - 2; prank[0] = -1; npush = 1; }
+        }
+        // append: exclusive prefix of the push counts over the lanes
+        int incl = npush;
+        for (int off = 1; off < 64; off <<= 1) { const int o = __shfl_up(incl, off); if ((int)lane >= off) incl += o; }
+        const int total = __shfl(incl, 63);
+        int at = count + incl - npush;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            if (j < npush && at < RTX_WIDE_CAP) {
+                v4i a; a.x = __double2loint(pe[j]); a.y = __double2hiint(pe[j]); a.z = pr[j]; a.w = pc[j];
+                unsigned long long k2 = key; int sh = shift;
+                if (prank[j] >= 0) { k2 = key | ((unsigned long long)(unsigned)prank[j] << (shift > 0 ? shift : 0)); sh = shift - 2; }
+                v4i bb; bb.x = (int)(unsigned)k2; bb.y = (int)(unsigned)(k2 >> 32); bb.z = sh; bb.w = 0;
+                F[2 * at] = a; F[2 * at + 1] = bb;
+                at++;
+            }
+        }
+        count += total;
+        if (count > RTX_WIDE_CAP) count = RTX_WIDE_CAP;      // (cannot happen: W leaves room for 4 W pushes)
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        __builtin_amdgcn_wave_barrier();
+        const double m = wave_min_d(best_t);
+        B = m < B ? m : B;
+        if (any_hit && B < stop) break;
+    }
+    // the winner: smallest t, then first in the reference's visiting order
+    const double tmin = wave_min_d(best_t);
+    const unsigned long long kmin = wave_min_u64(best_t == tmin ? best_key : ~0ull);
+    const int trmin = wave_min_i((best_t == tmin && best_key == kmin) ? best_tri : INT_MAX);
+    const int all_wmin = wave_min_i(wmin), all_wmax = wave_max_i(wmax);
+    if ((int)lane == src) {
+        if (tmin < INFINITY) { L.t_min = tmin; L.btri = trmin; }
+        L.word = min(L.word, all_wmin); L.whi = max(L.whi, all_wmax);
+        L.sp = 0;
+        L.state = LS_JOB_DONE;
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
+template <bool COUNT, bool WIDE>
+RTX_DEV bool traverse_steps(const Scene& S, const Wave& wv, Lane& L, glob_v4i* __restrict__ stk, unsigned* inst_bits,
                             const int service_threshold, const bool refillable, Tally& tl) {
     const unsigned lane = wv.lane;
     const unsigned n_summary = rtx_summary_words(S.n_insts);
@@ -973,6 +1190,8 @@ RTX_DEV void traverse_steps(const Scene& S, const Wave& wv, Lane& L, glob_v4i* _
         const unsigned long long m_wait = __ballot(L.state == LS_NEED_JOB || L.state == LS_JOB_DONE ||
                                                    (refillable && L.state == LS_EMPTY));
         if (__popcll(m_wait) >= service_threshold) break;
+        // the generation has drained and this wave holds its last few jobs: the caller finishes them wave-wide
+        if (WIDE && !refillable && __popcll(m_job) <= RTX_WIDE_LANES) return true;
         if (COUNT) {
             const int nl = __popcll(__ballot(at_leaf)), nj = __popcll(m_job);
             if (lane == 0) {
@@ -1133,9 +1352,15 @@ RTX_DEV void traverse_steps(const Scene& S, const Wave& wv, Lane& L, glob_v4i* _
         }
         if (COUNT) tl.clk_pop += (unsigned long long)(clock64() - p0);
     }
+    return false;
 }
 
-template <bool COUNT>
+// WIDE: the variant for generations of at most RTX_WIDE_MAX_RAYS rays, whose last jobs are
+// traversed wave-wide (wide_job).  Both variants are launched for every generation and exactly
+// one of them does the work; the other returns at once.  (Two kernels rather than one branch:
+// with wide_job compiled into it, the register allocation of the main loop suffers, and the
+// main variant is the one that matters for every generation of size.)
+template <bool COUNT, bool WIDE>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RTX_TRACE_WAVES, RTX_TRACE_WAVES)))
 k_trace(const Launch* __restrict__ Lp, GenCtrl* ctrl, const int gen, double* __restrict__ accum,
         rtx_hit_id* __restrict__ aov, Counters* __restrict__ counters) {
@@ -1153,6 +1378,10 @@ k_trace(const Launch* __restrict__ Lp, GenCtrl* ctrl, const int gen, double* __r
     unsigned n_in;
     if (gen == 0) n_in = (unsigned)F.n_items0;
     else { items.load(me, qin.sub_capacity); n_in = items.n_in; }
+    if (!COUNT) {
+        const bool tiny = Lp->wide_ok != 0 && n_in <= RTX_WIDE_MAX_RAYS;
+        if (tiny != WIDE) return;
+    }
     Tally tl = {};
     const long long clk_begin = COUNT ? clock64() : 0;
 
@@ -1236,7 +1465,15 @@ k_trace(const Launch* __restrict__ Lp, GenCtrl* ctrl, const int gen, double* __r
         }
         if (m_trav == 0ull) break;
         const long long c1 = COUNT ? clock64() : 0;
-        traverse_steps<COUNT>(S, wv, L, stk, inst_bits, service_threshold, !drained, tl);
+        const bool go_wide = traverse_steps<COUNT, WIDE>(S, wv, L, stk, inst_bits, service_threshold, !drained, tl);
+        if (WIDE && go_wide) {
+            unsigned long long m = __ballot(L.state == LS_IN_JOB);
+            while (m != 0ull) {
+                const int src = __ffsll((long long)m) - 1;
+                m &= m - 1ull;
+                wide_job(S, wv, L, stk, inst_bits, Lp->inst_words, src);
+            }
+        }
         if (COUNT) tl.clk_trav += (unsigned long long)(clock64() - c1);
     }
 
