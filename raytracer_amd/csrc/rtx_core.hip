@@ -732,7 +732,9 @@ int rtx_render(rtx_scene* sc, const rtx_camera* cam, int32_t tw, int32_t th, int
         launch.service_threshold = sc->dev.n_insts >= 256 ? RTX_SERVICE_THRESHOLD_INSTANCED : RTX_SERVICE_THRESHOLD;
         // wave-wide traversal of a drained generation's last jobs: its visiting-order keys hold 26 record levels
         launch.wide_ok = (sc->record_levels <= 26 && !getenv("RTX_AMD_NO_WIDE")) ? 1u : 0u;
-        launch.pad_launch = 0;
+        // ... and, in scenes that are not dominated by instance replay, of the long-running jobs of
+        // every generation's drained waves (a kernel variant of its own; see k_trace)
+        launch.wide_old = (launch.wide_ok && sc->dev.n_insts < 256 && !getenv("RTX_AMD_NO_WIDE_OLD")) ? 1u : 0u;
         HIP_TRY(sc->launch.ensure(sizeof(Launch)));
         // pageable source: the copy is staged before the call returns, so `launch` may go out of scope
         HIP_TRY(hipMemcpyAsync(sc->launch.p, &launch, sizeof launch, hipMemcpyHostToDevice, sc->stream));
@@ -757,15 +759,18 @@ int rtx_render(rtx_scene* sc, const rtx_camera* cam, int32_t tw, int32_t th, int
             if (gen == 0) blocks = (unsigned)std::min<int64_t>(persistent_blocks, (n_items0 + 255) / 256);
             rtx_hit_id* aov = (gen == 0 && hit_ids) ? (rtx_hit_id*)sc->aov.p : nullptr;
             if (sc->counters_on)
-                hipLaunchKernelGGL((k_trace<true, false>), dim3(blocks), dim3(256), 0, sc->stream, lp, (GenCtrl*)sc->ctrl.p, gen,
+                hipLaunchKernelGGL((k_trace<true, 0>), dim3(blocks), dim3(256), 0, sc->stream, lp, (GenCtrl*)sc->ctrl.p, gen,
                                    (double*)sc->accum.p, aov, (Counters*)sc->counters.p + gen);
+            else if (launch.wide_old)
+                hipLaunchKernelGGL((k_trace<false, 1>), dim3(blocks), dim3(256), 0, sc->stream, lp, (GenCtrl*)sc->ctrl.p, gen,
+                                   (double*)sc->accum.p, aov, (Counters*)nullptr);
             else
-                hipLaunchKernelGGL((k_trace<false, false>), dim3(blocks), dim3(256), 0, sc->stream, lp, (GenCtrl*)sc->ctrl.p, gen,
+                hipLaunchKernelGGL((k_trace<false, 0>), dim3(blocks), dim3(256), 0, sc->stream, lp, (GenCtrl*)sc->ctrl.p, gen,
                                    (double*)sc->accum.p, aov, (Counters*)nullptr);
             HIP_TRY(hipEventRecord(gev[2 * gen + 1], sc->stream));
             // the variant for tiny generations (one of the two returns at once; see k_trace)
             if (!sc->counters_on && launch.wide_ok)
-                hipLaunchKernelGGL((k_trace<false, true>), dim3(blocks), dim3(256), 0, sc->stream, lp, (GenCtrl*)sc->ctrl.p, gen,
+                hipLaunchKernelGGL((k_trace<false, 2>), dim3(blocks), dim3(256), 0, sc->stream, lp, (GenCtrl*)sc->ctrl.p, gen,
                                    (double*)sc->accum.p, aov, (Counters*)nullptr);
             // the last generation holds shadow rays only: nothing left to shade
             if (gen + 1 < G)

@@ -197,7 +197,9 @@ struct Launch {
     // Lanes waiting for service that make a wave of the trace kernel leave its traversal loop.
     uint32_t service_threshold;
     // The records are shallow enough (<= 26 levels) for the wave-wide traversal's visiting-order keys.
-    uint32_t wide_ok, pad_launch;
+    uint32_t wide_ok;
+    // In generations of size, drained waves finish their long-running jobs wave-wide as well.
+    uint32_t wide_old;
 };
 
 struct Counters {

@@ -455,7 +455,7 @@ struct Lane {
     int par;
     int cur_ref, cur_cnt, sp, btri;
     int state;
-    int age;                // traversal steps spent on the current ray (maintained when counters are on)
+    int age;                // traversal steps spent on the current job (with counters on: on the current ray)
     v4i top;                // top stack entry (valid while sp > 0)
 };
 
@@ -551,6 +551,7 @@ RTX_DEV bool job_next(const Scene& S, Lane& L, const RecOut& out, unsigned* inst
                     if (box_enter(tl_min, tl_max, ws, enter) && (L.t_min >= enter)) {
                         L.obj = -1;                                  // marks the job as the TLAS walk
                         L.is_shadow &= 1;
+                        if (!COUNT) L.age = 0;
                         L.orig_t_min = L.t_min;
                         L.ro = L.o; L.rd = L.d; L.ix = ws.ix; L.iy = ws.iy; L.iz = ws.iz; L.par = ws.par;
                         L.cur_ref = S.tl_key; L.cur_cnt = 0; L.sp = 0; L.btri = -1;
@@ -606,6 +607,7 @@ RTX_DEV bool job_next(const Scene& S, Lane& L, const RecOut& out, unsigned* inst
         L.obj = oi;
         L.orig_t_min = L.t_min;
         L.is_shadow &= 1;
+        if (!COUNT) L.age = 0;       // (steps of the job; with counters on: of the ray, for the histogram)
         if (!COUNT && L.is_shadow && !(flags & OBJ_XF)) {
             // A shadow ray asks only whether something lies in front of the light
             // (utils.cpp:1066-1084: hit && distance < |L - P|).  Once a hit has been accepted
@@ -971,9 +973,14 @@ RTX_DEV void cand_swap(Cand& a, Cand& b, bool doit) {
 // top), then two bits per record level = the child's position in the reference's near-to-far
 // order; within a leaf the triangle's position.  Every triangle is tested against the incoming
 // bound and the minimum of (t, key, triangle) is taken at the end.
+#ifndef RTX_WIDE_LANES
 #define RTX_WIDE_LANES 6             // at most this many unfinished jobs in a drained wave: run them wave-wide
+#endif
 #ifndef RTX_WIDE_MAX_RAYS
 #define RTX_WIDE_MAX_RAYS 512        // generations with at most this many rays use it
+#endif
+#ifndef RTX_WIDE_AGE
+#define RTX_WIDE_AGE 64              // in a generation of size: only jobs that have taken this many steps already
 #endif
 #define RTX_WIDE_CAP 480             // frontier entries (32 bytes) in the wave's LDS rows
 #define RTX_WIDE_KEY_SHIFT 52        // first record level's two key bits; ten bits above them for the starting rank
@@ -998,25 +1005,33 @@ RTX_DEV int wave_max_i(int v) {
     return v;
 }
 
-RTX_DEV void wide_job(const Scene& S, const Wave& wv, Lane& L, glob_v4i* stk, unsigned* inst_bits, const unsigned inst_words,
-                      const int src) {
+// What the wave needs of the owner's lane, and what it hands back.  Passed by value: the function is
+// not inlined (inlined, its registers spoil the allocation of the traversal loop around the call).
+struct WideIn { double rox, roy, roz, rdx, rdy, rdz, ix, iy, iz, t_min, stop; int par, shadow, sp, cur_ref, cur_cnt; v4i top; };
+struct WideOut { double t_min; int btri, wmin, wmax; };
+
+__device__ __attribute__((noinline)) WideOut wide_job(const Scene& S, const Wave wv, const WideIn L, glob_v4i* stk, unsigned* inst_bits,
+                                                      const unsigned inst_words, const int src) {
     const unsigned lane = wv.lane;
     const char* const blas = S.blas;
     const unsigned n_summary = rtx_summary_words(S.n_insts);
     // the owner's job, wave-uniform
     Slab sl;
-    sl.ox = bcast_d(L.ro.x, src); sl.oy = bcast_d(L.ro.y, src); sl.oz = bcast_d(L.ro.z, src);
+    sl.ox = bcast_d(L.rox, src); sl.oy = bcast_d(L.roy, src); sl.oz = bcast_d(L.roz, src);
     sl.ix = bcast_d(L.ix, src); sl.iy = bcast_d(L.iy, src); sl.iz = bcast_d(L.iz, src);
     sl.par = __builtin_amdgcn_readlane(L.par, src);
     const V3 ro = mk(sl.ox, sl.oy, sl.oz);
-    const V3 rd = mk(bcast_d(L.rd.x, src), bcast_d(L.rd.y, src), bcast_d(L.rd.z, src));
+    const V3 rd = mk(bcast_d(L.rdx, src), bcast_d(L.rdy, src), bcast_d(L.rdz, src));
     const double b_init = bcast_d(L.t_min, src);
-    const double stop = bcast_d(L.orig_t_min, src);
-    const bool any_hit = (__builtin_amdgcn_readlane(L.is_shadow, src) & 2) != 0;
+    const double stop = bcast_d(L.stop, src);
+    const bool any_hit = (__builtin_amdgcn_readlane(L.shadow, src) & 2) != 0;
     const int o_sp = __builtin_amdgcn_readlane(L.sp, src);
-    const int delta = src - (int)lane;
-    const glob_v4i* o_stk = stk + (long)delta * RTX_STACK;
-    unsigned* o_bits = inst_bits + (long)delta * (long)inst_words;
+    const unsigned long long stk_a = (unsigned long long)(size_t)stk, bits_a = (unsigned long long)(size_t)inst_bits;
+    const glob_v4i* o_stk = (const glob_v4i*)(size_t)(((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(stk_a >> 32), src) << 32) |
+                                                       (unsigned)__builtin_amdgcn_readlane((int)stk_a, src));
+    unsigned* o_bits = (unsigned*)(size_t)(((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(bits_a >> 32), src) << 32) |
+                                           (unsigned)__builtin_amdgcn_readlane((int)bits_a, src));
+    (void)inst_words;
     const bool cull = S.cull != 0;
     const double isect_eps = S.isect_eps;
 
@@ -1162,17 +1177,34 @@ RTX_DEV void wide_job(const Scene& S, const Wave& wv, Lane& L, glob_v4i* stk, un
     const unsigned long long kmin = wave_min_u64(best_t == tmin ? best_key : ~0ull);
     const int trmin = wave_min_i((best_t == tmin && best_key == kmin) ? best_tri : INT_MAX);
     const int all_wmin = wave_min_i(wmin), all_wmax = wave_max_i(wmax);
-    if ((int)lane == src) {
-        if (tmin < INFINITY) { L.t_min = tmin; L.btri = trmin; }
-        L.word = min(L.word, all_wmin); L.whi = max(L.whi, all_wmax);
-        L.sp = 0;
-        L.state = LS_JOB_DONE;
-    }
+    WideOut out;
+    out.t_min = tmin; out.btri = trmin; out.wmin = all_wmin; out.wmax = all_wmax;
     __builtin_amdgcn_wave_barrier();
+    return out;
 }
 
-template <bool COUNT, bool WIDE>
-RTX_DEV bool traverse_steps(const Scene& S, const Wave& wv, Lane& L, glob_v4i* __restrict__ stk, unsigned* inst_bits,
+// Run the jobs of the lanes in `m` wave-wide, one after the other.
+RTX_DEV void wide_jobs(const Scene& S, const Wave& wv, Lane& L, glob_v4i* stk, unsigned* inst_bits, unsigned inst_words,
+                       unsigned long long m) {
+    WideIn in;
+    in.rox = L.ro.x; in.roy = L.ro.y; in.roz = L.ro.z; in.rdx = L.rd.x; in.rdy = L.rd.y; in.rdz = L.rd.z;
+    in.ix = L.ix; in.iy = L.iy; in.iz = L.iz; in.t_min = L.t_min; in.stop = L.orig_t_min;
+    in.par = L.par; in.shadow = L.is_shadow; in.sp = L.sp; in.cur_ref = L.cur_ref; in.cur_cnt = L.cur_cnt; in.top = L.top;
+    while (m != 0ull) {
+        const int src = __ffsll((long long)m) - 1;
+        m &= m - 1ull;
+        const WideOut out = wide_job(S, wv, in, stk, inst_bits, inst_words, src);
+        if ((int)wv.lane == src) {
+            if (out.t_min < INFINITY) { L.t_min = out.t_min; L.btri = out.btri; }
+            L.word = min(L.word, out.wmin); L.whi = max(L.whi, out.wmax);
+            L.sp = 0;
+            L.state = LS_JOB_DONE;
+        }
+    }
+}
+
+template <bool COUNT, int WIDE>
+RTX_DEV unsigned long long traverse_steps(const Scene& S, const Wave& wv, Lane& L, glob_v4i* __restrict__ stk, unsigned* inst_bits,
                             const int service_threshold, const bool refillable, Tally& tl) {
     const unsigned lane = wv.lane;
     const unsigned n_summary = rtx_summary_words(S.n_insts);
@@ -1191,7 +1223,10 @@ RTX_DEV bool traverse_steps(const Scene& S, const Wave& wv, Lane& L, glob_v4i* _
                                                    (refillable && L.state == LS_EMPTY));
         if (__popcll(m_wait) >= service_threshold) break;
         // the generation has drained and this wave holds its last few jobs: the caller finishes them wave-wide
-        if (WIDE && !refillable && __popcll(m_job) <= RTX_WIDE_LANES) return true;
+        if (!COUNT && WIDE != 0 && !refillable && __popcll(m_job) <= RTX_WIDE_LANES) {
+            const unsigned long long m_old = WIDE == 2 ? m_job : __ballot(in_job && L.age >= RTX_WIDE_AGE);
+            if (m_old != 0ull) return m_old;
+        }
         if (COUNT) {
             const int nl = __popcll(__ballot(at_leaf)), nj = __popcll(m_job);
             if (lane == 0) {
@@ -1224,7 +1259,7 @@ RTX_DEV bool traverse_steps(const Scene& S, const Wave& wv, Lane& L, glob_v4i* _
 
         bool need_pop = false;
         if (in_job) {
-            if (COUNT) L.age++;
+            L.age++;
             if (!at_leaf) {
                 // ---- collapsed inner node: up to four grandchildren of a binary node ------------
                 if (COUNT) { if (L.obj == -1) tl.tlas_visits++; else tl.node_visits++; }
@@ -1352,15 +1387,17 @@ RTX_DEV bool traverse_steps(const Scene& S, const Wave& wv, Lane& L, glob_v4i* _
         }
         if (COUNT) tl.clk_pop += (unsigned long long)(clock64() - p0);
     }
-    return false;
+    return 0ull;
 }
 
-// WIDE: the variant for generations of at most RTX_WIDE_MAX_RAYS rays, whose last jobs are
-// traversed wave-wide (wide_job).  Both variants are launched for every generation and exactly
-// one of them does the work; the other returns at once.  (Two kernels rather than one branch:
-// with wide_job compiled into it, the register allocation of the main loop suffers, and the
-// main variant is the one that matters for every generation of size.)
-template <bool COUNT, bool WIDE>
+// WIDE = 2: the variant for generations of at most RTX_WIDE_MAX_RAYS rays, all of whose last
+// jobs are traversed wave-wide (wide_job).  It and a main variant are launched for every
+// generation and exactly one of them does the work; the other returns at once.
+// WIDE = 1: main variant in which drained waves finish their long-running jobs wave-wide too.
+// WIDE = 0: main variant without any of it.  (Variants rather than branches: the mere presence
+// of the call changes the register allocation of the code around it -- the service passes pay
+// for it, which scenes dominated by instance replay notice -- so the host picks per scene.)
+template <bool COUNT, int WIDE>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RTX_TRACE_WAVES, RTX_TRACE_WAVES)))
 k_trace(const Launch* __restrict__ Lp, GenCtrl* ctrl, const int gen, double* __restrict__ accum,
         rtx_hit_id* __restrict__ aov, Counters* __restrict__ counters) {
@@ -1380,7 +1417,7 @@ k_trace(const Launch* __restrict__ Lp, GenCtrl* ctrl, const int gen, double* __r
     else { items.load(me, qin.sub_capacity); n_in = items.n_in; }
     if (!COUNT) {
         const bool tiny = Lp->wide_ok != 0 && n_in <= RTX_WIDE_MAX_RAYS;
-        if (tiny != WIDE) return;
+        if (tiny != (WIDE == 2)) return;
     }
     Tally tl = {};
     const long long clk_begin = COUNT ? clock64() : 0;
@@ -1465,15 +1502,8 @@ k_trace(const Launch* __restrict__ Lp, GenCtrl* ctrl, const int gen, double* __r
         }
         if (m_trav == 0ull) break;
         const long long c1 = COUNT ? clock64() : 0;
-        const bool go_wide = traverse_steps<COUNT, WIDE>(S, wv, L, stk, inst_bits, service_threshold, !drained, tl);
-        if (WIDE && go_wide) {
-            unsigned long long m = __ballot(L.state == LS_IN_JOB);
-            while (m != 0ull) {
-                const int src = __ffsll((long long)m) - 1;
-                m &= m - 1ull;
-                wide_job(S, wv, L, stk, inst_bits, Lp->inst_words, src);
-            }
-        }
+        const unsigned long long m_wide = traverse_steps<COUNT, WIDE>(S, wv, L, stk, inst_bits, service_threshold, !drained, tl);
+        if (!COUNT && WIDE != 0 && m_wide != 0ull) wide_jobs(S, wv, L, stk, inst_bits, Lp->inst_words, m_wide);
         if (COUNT) tl.clk_trav += (unsigned long long)(clock64() - c1);
     }
 
