@@ -1146,7 +1146,14 @@ __device__ __attribute__((noinline)) WideOut wide_job(const Scene& S, const Wave
             if (two && !culled1 && tri_test(tq, ro, rd, b_init, isect_eps, t, b, g2)) {
                 if (t < best_t || (t == best_t && (key < best_key || (key == best_key && ref + 1 < best_tri)))) { best_t = t; best_key = key; best_tri = ref + 1; }
             }
-            if (cnt > 2) { pe[0] = __hiloint2double(ea.y, ea.x); pr[0] = ref + 2; pc[0] = cnt - 2; prank[0] = -1; npush = 1; }
+            if (cnt > 2) {
+                // the rest of a long leaf (a mesh without a BVH is one leaf): in two halves, so that
+                // the lanes working on it double with every round
+                const int rest = cnt - 2;
+                const int h = rest > 2 ? ((rest >> 1) + 1) & ~1 : rest;        // an even number of triangles first
+                pe[0] = __hiloint2double(ea.y, ea.x); pr[0] = ref + 2; pc[0] = h; prank[0] = -1; npush = 1;
+                if (rest > h) { pe[1] = pe[0]; pr[1] = ref + 2 + h; pc[1] = rest - h; prank[1] = -1; npush = 2; }
+            }
         }
         // append: exclusive prefix of the push counts over the lanes
         int incl = npush;
