@@ -673,6 +673,17 @@ int rtx_render(rtx_scene* sc, const rtx_camera* cam, int32_t tw, int32_t th, int
     const int64_t n_local_px = (int64_t)g.n_sel * tw * th;
     if (n_items0 > (int64_t)0x7FFFFFF0 || n_local_px * 3 > (int64_t)0x7FFFFFF0) return fail(RTX_ELIMIT, "frame too large for one call");
     F.n_items0 = (int32_t)n_items0;
+    {
+        const uint64_t nb = (uint64_t)(n_items0 / 64);
+        uint64_t mul = 1;
+        if (nb > 8 && !getenv("RTX_AMD_NO_SCATTER")) {
+            auto gcd = [](uint64_t a, uint64_t b) { while (b) { const uint64_t t = a % b; a = b; b = t; } return a; };
+            mul = (uint64_t)((double)nb * 0.6180339887498949) | 1u;
+            while (gcd(mul, nb) != 1) mul += 2;
+            mul %= nb;
+        }
+        F.block_mul = (uint32_t)mul; F.n_blocks = (uint32_t)nb;
+    }
 
     const int G = sc->dev.max_depth + 2;
     HIP_TRY(sc->accum.ensure((size_t)n_local_px * 3 * sizeof(double)));

@@ -139,6 +139,10 @@ struct Frame {
     int32_t width, height;
     int32_t tile_w, tile_h, tiles_x, tile_first, tile_stride;
     int32_t n_items0;       // generation-0 work items: selected tiles x 8x8 blocks x 64
+    // 8x8 pixel blocks are handed out in a scattered order (block of items i = i * block_mul mod
+    // n_blocks, block_mul coprime to n_blocks): neighbouring blocks have rays of similar length,
+    // and a wave that takes several of them in a row is left with nothing but long rays at the end.
+    uint32_t block_mul, n_blocks;
 };
 
 // One queued ray, 96 bytes = six 16-byte pieces.  meta = depth | (beer_material + 1) << 8;

@@ -804,7 +804,7 @@ RTX_DEV void add_color(double* accum, unsigned pixel, V3 c) {
 // so the rays of a wave are coherent.  Returns false for padding items outside the image.
 RTX_DEV bool primary_pixel(const Frame& F, unsigned item, int& px, int& py, unsigned& local_pixel) {
     const int bpt_x = (F.tile_w + 7) >> 3, bpt_y = (F.tile_h + 7) >> 3;
-    const unsigned blk = item >> 6, l = item & 63u;
+    const unsigned blk = (unsigned)(((unsigned long long)(item >> 6) * F.block_mul) % F.n_blocks), l = item & 63u;
     const unsigned bpt = (unsigned)(bpt_x * bpt_y);
     const unsigned k = blk / bpt, b = blk % bpt;
     const int tx = (int)(b % (unsigned)bpt_x) * 8 + (int)(l & 7u);
