@@ -430,6 +430,9 @@ enum { LS_EMPTY = 0, LS_NEED_JOB = 1, LS_JOB_DONE = 2, LS_IN_JOB = 3 };
 #define RTX_SERVICE_REPS 4           // rounds of a service pass: lanes whose ray ended in one round are refilled in the next
 #endif
 #define RTX_SPARSE_LANES 2           // at most this many traversing lanes: load records directly
+#ifndef RTX_SCATTER_SHIFT
+#define RTX_SCATTER_SHIFT 4          // rays of later generations are handed out in scattered groups of 16
+#endif
 #define RTX_CHUNK 256                // rays a wave claims per atomic
 #ifndef RTX_TRACE_WAVES
 #define RTX_TRACE_WAVES 2            // waves per SIMD the trace kernel is compiled for (2: 256 VGPRs)
@@ -764,6 +767,7 @@ RTX_DEV void emit(const Queue& q, GenCtrl* next, unsigned sub, bool shadow, bool
 struct GenItems {
     unsigned rad_end[RTX_NSUB], sh_end[RTX_NSUB];     // cumulative counts through sub-queue q
     unsigned n_rad, n_in, sub_capacity;
+    unsigned grp_r, grp_s, mul_r, mul_s;
 
     RTX_DEV void load(const GenCtrl* me, unsigned sub_cap) {
         sub_capacity = sub_cap;
@@ -778,11 +782,33 @@ struct GenItems {
             rad_end[q] = r_acc; sh_end[q] = s_acc;
         }
         n_rad = r_acc; n_in = r_acc + s_acc;
+        // scattered hand-out order (see slot): multipliers coprime to the group counts
+        grp_r = n_rad >> RTX_SCATTER_SHIFT; grp_s = (n_in - n_rad) >> RTX_SCATTER_SHIFT;
+        mul_r = coprime_near_golden(grp_r); mul_s = coprime_near_golden(grp_s);
+    }
+    RTX_DEV static unsigned coprime_near_golden(unsigned n) {
+        if (n < 8u) return 1u;
+        unsigned m = (unsigned)((unsigned long long)n * 2654435769ull >> 32) | 1u;       // n / golden ratio, odd
+        while (true) {
+            unsigned a = m, b = n;
+            while (b != 0u) { const unsigned t = a % b; a = b; b = t; }
+            if (a == 1u) return m % n;
+            m += 2u;
+        }
     }
     // queue slot of work item w < n_in
+    // Work items are handed out in a scattered order: groups of 2^RTX_SCATTER_SHIFT consecutive
+    // rays of a class are permuted (group g -> g * mul mod groups).  Rays emitted together are of
+    // similar length; scattered, every wave gets its share of the long ones, and few enough of
+    // them at the end to finish them wave-wide.
     RTX_DEV unsigned slot(unsigned w, bool& is_shadow) const {
         is_shadow = w >= n_rad;
-        const unsigned v = is_shadow ? w - n_rad : w;
+        unsigned v = is_shadow ? w - n_rad : w;
+        {
+            const unsigned grp = is_shadow ? grp_s : grp_r, mul = is_shadow ? mul_s : mul_r;
+            const unsigned g = v >> RTX_SCATTER_SHIFT;
+            if (g < grp) v = (unsigned)(((unsigned long long)g * mul) % grp) << RTX_SCATTER_SHIFT | (v & ((1u << RTX_SCATTER_SHIFT) - 1u));
+        }
         unsigned q = 0, prev = 0;
 #pragma unroll
         for (int k = 0; k + 1 < RTX_NSUB; k++) {
