@@ -674,7 +674,7 @@ int rtx_render(rtx_scene* sc, const rtx_camera* cam, int32_t tw, int32_t th, int
     if (n_items0 > (int64_t)0x7FFFFFF0 || n_local_px * 3 > (int64_t)0x7FFFFFF0) return fail(RTX_ELIMIT, "frame too large for one call");
     F.n_items0 = (int32_t)n_items0;
     {
-        const uint64_t nb = (uint64_t)(n_items0 / 64);
+        const uint64_t nb = (uint64_t)(n_items0 >> RTX_SCATTER0_SHIFT);
         uint64_t mul = 1;
         if (nb > 8 && !getenv("RTX_AMD_NO_SCATTER")) {
             auto gcd = [](uint64_t a, uint64_t b) { while (b) { const uint64_t t = a % b; a = b; b = t; } return a; };

@@ -430,6 +430,9 @@ enum { LS_EMPTY = 0, LS_NEED_JOB = 1, LS_JOB_DONE = 2, LS_IN_JOB = 3 };
 #define RTX_SERVICE_REPS 4           // rounds of a service pass: lanes whose ray ended in one round are refilled in the next
 #endif
 #define RTX_SPARSE_LANES 2           // at most this many traversing lanes: load records directly
+#ifndef RTX_SCATTER0_SHIFT
+#define RTX_SCATTER0_SHIFT 6         // generation 0: whole 8x8 pixel blocks (64 items) are scattered
+#endif
 #ifndef RTX_SCATTER_SHIFT
 #define RTX_SCATTER_SHIFT 4          // rays of later generations are handed out in scattered groups of 16
 #endif
@@ -830,7 +833,10 @@ RTX_DEV void add_color(double* accum, unsigned pixel, V3 c) {
 // so the rays of a wave are coherent.  Returns false for padding items outside the image.
 RTX_DEV bool primary_pixel(const Frame& F, unsigned item, int& px, int& py, unsigned& local_pixel) {
     const int bpt_x = (F.tile_w + 7) >> 3, bpt_y = (F.tile_h + 7) >> 3;
-    const unsigned blk = (unsigned)(((unsigned long long)(item >> 6) * F.block_mul) % F.n_blocks), l = item & 63u;
+    // (scattered in groups of 2^RTX_SCATTER0_SHIFT items: F.n_blocks counts those groups)
+    const unsigned it2 = (unsigned)(((unsigned long long)(item >> RTX_SCATTER0_SHIFT) * F.block_mul) % F.n_blocks) << RTX_SCATTER0_SHIFT |
+                         (item & ((1u << RTX_SCATTER0_SHIFT) - 1u));
+    const unsigned blk = it2 >> 6, l = it2 & 63u;
     const unsigned bpt = (unsigned)(bpt_x * bpt_y);
     const unsigned k = blk / bpt, b = blk % bpt;
     const int tx = (int)(b % (unsigned)bpt_x) * 8 + (int)(l & 7u);
