@@ -745,6 +745,7 @@ int rtx_render(rtx_scene* sc, const rtx_camera* cam, int32_t tw, int32_t th, int
         launch.wide_ok = (sc->record_levels <= 26 && !getenv("RTX_AMD_NO_WIDE")) ? 1u : 0u;
         // ... and, in scenes that are not dominated by instance replay, of the long-running jobs of
         // every generation's drained waves (a kernel variant of its own; see k_trace)
+        launch.chunk_max = sc->dev.n_insts >= 256 ? RTX_CHUNK_INSTANCED : RTX_CHUNK; launch.pad_launch = 0;
         launch.wide_old = (launch.wide_ok && sc->dev.n_insts < 256 && !getenv("RTX_AMD_NO_WIDE_OLD")) ? 1u : 0u;
         HIP_TRY(sc->launch.ensure(sizeof(Launch)));
         // pageable source: the copy is staged before the call returns, so `launch` may go out of scope

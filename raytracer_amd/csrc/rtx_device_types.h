@@ -204,6 +204,8 @@ struct Launch {
     uint32_t wide_ok;
     // In generations of size, drained waves finish their long-running jobs wave-wide as well.
     uint32_t wide_old;
+    // Largest number of rays a wave of the trace kernel claims at once.
+    uint32_t chunk_max, pad_launch;
 };
 
 struct Counters {

@@ -436,7 +436,10 @@ enum { LS_EMPTY = 0, LS_NEED_JOB = 1, LS_JOB_DONE = 2, LS_IN_JOB = 3 };
 #ifndef RTX_SCATTER_SHIFT
 #define RTX_SCATTER_SHIFT 4          // rays of later generations are handed out in scattered groups of 16
 #endif
-#define RTX_CHUNK 256                // rays a wave claims per atomic
+#ifndef RTX_CHUNK
+#define RTX_CHUNK 64                 // rays a wave claims per atomic, at most ...
+#define RTX_CHUNK_INSTANCED 256       // ... and in scenes dominated by instance replay
+#endif
 #ifndef RTX_TRACE_WAVES
 #define RTX_TRACE_WAVES 2            // waves per SIMD the trace kernel is compiled for (2: 256 VGPRs)
 #endif
@@ -1006,13 +1009,13 @@ RTX_DEV void cand_swap(Cand& a, Cand& b, bool doit) {
 // order; within a leaf the triangle's position.  Every triangle is tested against the incoming
 // bound and the minimum of (t, key, triangle) is taken at the end.
 #ifndef RTX_WIDE_LANES
-#define RTX_WIDE_LANES 6             // at most this many unfinished jobs in a drained wave: run them wave-wide
+#define RTX_WIDE_LANES 10            // at most this many unfinished jobs in a drained wave: run them wave-wide
 #endif
 #ifndef RTX_WIDE_MAX_RAYS
 #define RTX_WIDE_MAX_RAYS 512        // generations with at most this many rays use it
 #endif
 #ifndef RTX_WIDE_AGE
-#define RTX_WIDE_AGE 64              // in a generation of size: only jobs that have taken this many steps already
+#define RTX_WIDE_AGE 32              // in a generation of size: only jobs that have taken this many steps already
 #endif
 #define RTX_WIDE_CAP 480             // frontier entries (32 bytes) in the wave's LDS rows
 #define RTX_WIDE_KEY_SHIFT 52        // first record level's two key bits; ten bits above them for the starting rank
@@ -1467,7 +1470,8 @@ k_trace(const Launch* __restrict__ Lp, GenCtrl* ctrl, const int gen, double* __r
     // saw remaining), so that no wave is left with several rounds of rays when the others run dry.
     const unsigned n_waves = gridDim.x * (blockDim.x >> 6);
     unsigned chunk = (n_in + 2u * n_waves - 1u) / (2u * n_waves);
-    chunk = chunk < 1u ? 1u : (chunk > RTX_CHUNK ? RTX_CHUNK : chunk);
+    const unsigned chunk_max = Lp->chunk_max;
+    chunk = chunk < 1u ? 1u : (chunk > chunk_max ? chunk_max : chunk);
     unsigned chunk_next = 0, chunk_end = 0;      // wave-uniform
     bool drained = false;                        // wave-uniform: the generation has no rays left
 
@@ -1502,7 +1506,7 @@ k_trace(const Launch* __restrict__ Lp, GenCtrl* ctrl, const int gen, double* __r
                         else {
                             chunk_next = base; chunk_end = min(base + chunk, n_in);
                             const unsigned share = (n_in - chunk_end) / (2u * n_waves);
-                            chunk = share < 16u ? 16u : (share > RTX_CHUNK ? RTX_CHUNK : share);
+                            chunk = share < 16u ? 16u : (share > chunk_max ? chunk_max : share);
                             if (chunk > n_in) chunk = n_in;
                         }
                     }
