@@ -424,12 +424,16 @@ RTX_DEV void free_tri_hit(const Scene& S, V3 ro, V3 rd, int index, double& t_min
 // ---------------------------------------------------------------------------------------
 enum { LS_EMPTY = 0, LS_NEED_JOB = 1, LS_JOB_DONE = 2, LS_IN_JOB = 3 };
 
+#ifndef RTX_SERVICE_THRESHOLD
 #define RTX_SERVICE_THRESHOLD 24     // lanes waiting for service that trigger a service pass ...
+#endif
 #define RTX_SERVICE_THRESHOLD_INSTANCED 36   // ... and in scenes where a pass replays many instance candidates
 #ifndef RTX_SERVICE_REPS
 #define RTX_SERVICE_REPS 4           // rounds of a service pass: lanes whose ray ended in one round are refilled in the next
 #endif
+#ifndef RTX_SPARSE_LANES
 #define RTX_SPARSE_LANES 2           // at most this many traversing lanes: load records directly
+#endif
 #ifndef RTX_SCATTER0_SHIFT
 #define RTX_SCATTER0_SHIFT 6         // generation 0: whole 8x8 pixel blocks (64 items) are scattered
 #endif
