@@ -434,6 +434,9 @@ enum { LS_EMPTY = 0, LS_NEED_JOB = 1, LS_JOB_DONE = 2, LS_IN_JOB = 3 };
 #ifndef RTX_SPARSE_LANES
 #define RTX_SPARSE_LANES 2           // at most this many traversing lanes: load records directly
 #endif
+#ifndef RTX_LINEAR_INSTS
+#define RTX_LINEAR_INSTS 4           // up to this many instances are tried one after the other, without a TLAS walk (< 32)
+#endif
 #ifndef RTX_SCATTER0_SHIFT
 #define RTX_SCATTER0_SHIFT 6         // generation 0: whole 8x8 pixel blocks (64 items) are scattered
 #endif
@@ -558,7 +561,11 @@ RTX_DEV bool job_next(const Scene& S, Lane& L, const RecOut& out, unsigned* inst
                 // reference's own per-instance logic (world-box test against the then-current
                 // bound included).
                 L.word = INT_MAX; L.whi = -1; L.bits = 0u; L.sbits = 0u; L.sword = -1;
-                if (S.n_insts > 0) {
+                if (S.n_insts > 0 && S.n_insts <= RTX_LINEAR_INSTS) {
+                    // a handful of instances: every one is a candidate (the reference's own loop,
+                    // utils.cpp:756-790); a TLAS walk would cost more than it can save
+                    L.word = 0; L.bits = (1u << S.n_insts) - 1u; L.sword = 0; L.whi = 0;
+                } else if (S.n_insts > 0) {
                     double tl_min[3] = {S.tl_min[0], S.tl_min[1], S.tl_min[2]}, tl_max[3] = {S.tl_max[0], S.tl_max[1], S.tl_max[2]};
                     double enter;
                     if (box_enter(tl_min, tl_max, ws, enter) && (L.t_min >= enter)) {
