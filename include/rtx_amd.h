@@ -214,6 +214,21 @@ int rtx_build_bvh(int32_t device, const double* vertices, int64_t n_vertices, co
  * no longer change after that, so pictures and hit records are the same in both modes. */
 int rtx_scene_set_counters(rtx_scene* scene, int32_t enable);
 
+/* Consistent mode; default off.  It has no counterpart in the reference: it departs from the
+ * reference's results where those depend on two properties of its transformed-object code,
+ * and is not covered by the parity guarantee of the default mode.
+ *  - rayHitsMesh searches a transformed mesh or instance with the *world-space* bound against
+ *    *object-space* distances (utils.cpp:476-531), and a hit that turns out farther than the
+ *    bound is dropped but has already overwritten the record (utils.cpp:559-570): scaled
+ *    instances lose or gain hits.  In consistent mode the bound is carried into object space
+ *    with the ray and a dropped hit leaves no trace.
+ *  - isInShadow (utils.cpp:1066-1084) runs a closest-hit query.  In consistent mode a shadow ray
+ *    starts with the light's distance as its bound and ends at the first hit it accepts.
+ * Everything else (object order, tests, shading, roundings) is unchanged; scenes without
+ * transformed meshes and instances give the same picture in both modes.  Work counters
+ * (rtx_scene_set_counters) cannot be combined with it: rtx_render returns RTX_EINVAL. */
+int rtx_scene_set_consistent(rtx_scene* scene, int32_t enable);
+
 /* Cap, in bytes, of the two ray queues together (default 32 GiB). */
 int rtx_scene_set_queue_limit(rtx_scene* scene, int64_t bytes);
 

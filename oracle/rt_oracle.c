@@ -51,9 +51,18 @@ typedef struct {
 
 typedef struct { v3 o, d; int depth; } ray_t;
 
+/* consistent / any_hit: NOT reference behaviour.  They restate the device library's optional
+ * "consistent" mode (rtx_scene_set_consistent) so that this mode too has a CPU checker:
+ *  - a transformed mesh or instance is searched with the ray's bound carried into object
+ *    space (bound / |M^-1 d| as the reference normalises it), and a hit whose world distance
+ *    is not below the bound leaves bound and record untouched;
+ *  - a shadow ray starts with the light's distance as its bound and is occluded iff any hit
+ *    is accepted (any_hit: a transformed mesh accepts on the object-space test alone).
+ * With both flags 0 every function below is the reference's. */
 typedef struct {
     const rtx_scene_desc* s;
     rt_oracle_counters* c;
+    int consistent, any_hit;
 } ctx_t;
 
 /* ---- overloads.cpp:10-65 ------------------------------------------------------------ */
@@ -252,12 +261,19 @@ static int mesh_hit(const ctx_t* cx, const ray_t* ray, int mesh_index, int xform
     double invLen = 1.0 / sqrtf(lenSq);
     oray.d = V(od.x * invLen, od.y * invLen, od.z * invLen);
     oray.depth = ray->depth;
-    if (!bvh_traverse(cx, &oray, mesh, t_min, is, mesh_index, material)) return 0;
+    isect_t before;
+    if (cx->consistent) {
+        before = *is;
+        double bound = *t_min / invLen;
+        if (!bvh_traverse(cx, &oray, mesh, &bound, is, mesh_index, material)) return 0;
+        if (cx->any_hit) return 1;
+    } else if (!bvh_traverse(cx, &oray, mesh, t_min, is, mesh_index, material)) return 0;
 
     v3 wp = xf_point(xf->transform, is->point);
     double dx = wp.x - ray->o.x, dy = wp.y - ray->o.y, dz = wp.z - ray->o.z;
     double worldDistance = sqrtf(dx * dx + dy * dy + dz * dz);
     if (worldDistance >= original_t_min) {
+        if (cx->consistent) *is = before;
         *t_min = original_t_min;
         return 0;
     }
@@ -391,10 +407,9 @@ static int sphere_hit(const ctx_t* cx, const ray_t* ray, int index, double* t_mi
 }
 
 /* ---- utils.cpp:671-865 -------------------------------------------------------------- */
-static isect_t intersect(const ctx_t* cx, const ray_t* ray) {
+static isect_t intersect_within(const ctx_t* cx, const ray_t* ray, double t_min) {
     const rtx_scene_desc* s = cx->s;
     cx->c->rays++;
-    double t_min = DBL_MAX;
     isect_t is;
     memset(&is, 0, sizeof is);
     is.kind = RTX_KIND_NONE; is.container = -1; is.face = -1; is.material = -1; is.src = -1;
@@ -478,6 +493,8 @@ static isect_t intersect(const ctx_t* cx, const ray_t* ray) {
     return is;
 }
 
+static isect_t intersect(const ctx_t* cx, const ray_t* ray) { return intersect_within(cx, ray, DBL_MAX); }
+
 static v3 pixel_color(const ctx_t* cx, const ray_t* ray, const isect_t* is);
 
 /* utils.cpp:1167-1182 */
@@ -544,6 +561,11 @@ static int in_shadow(const ctx_t* cx, const rtx_light* light, const isect_t* is)
     sr.d = normalize(vsub(L, is->point));
     sr.depth = 0;
     cx->c->shadow_rays++;
+    if (cx->consistent) {
+        ctx_t any = *cx;
+        any.any_hit = 1;
+        return intersect_within(&any, &sr, sqrt(dot(vsub(L, is->point), vsub(L, is->point)))).hit;
+    }
     isect_t si = intersect(cx, &sr);
     double distToLight = sqrt(dot(vsub(L, is->point), vsub(L, is->point)));
     return si.hit && si.distance < distToLight;
@@ -655,13 +677,13 @@ typedef struct {
     const rtx_camera* cam;
     uint8_t* rgb;
     rtx_hit_id* hits;
-    int tid, nthreads;
+    int tid, nthreads, consistent;
     rt_oracle_counters c;
 } job_t;
 
 static void* worker(void* arg) {
     job_t* j = (job_t*)arg;
-    ctx_t cx = {j->s, &j->c};
+    ctx_t cx = {j->s, &j->c, j->consistent, 0};
     int w = j->cam->width, h = j->cam->height;
     for (int y = j->tid; y < h; y += j->nthreads) {
         for (int x = 0; x < w; x++) {
@@ -694,8 +716,8 @@ static void* worker(void* arg) {
 
 /* Render one camera on `nthreads` host threads (rows interleaved).  rgb / hits / counters
  * may be NULL.  Returns elapsed milliseconds, or a negative value on bad arguments. */
-double rt_oracle_render(const rtx_scene_desc* s, const rtx_camera* cam, uint8_t* rgb,
-                        rtx_hit_id* hits, rt_oracle_counters* counters, int nthreads) {
+static double render(const rtx_scene_desc* s, const rtx_camera* cam, uint8_t* rgb,
+                     rtx_hit_id* hits, rt_oracle_counters* counters, int nthreads, int consistent) {
     if (!s || !cam || cam->width <= 0 || cam->height <= 0) return -1.0;
     if (nthreads < 1) nthreads = 1;
     if (nthreads > 256) nthreads = 256;
@@ -705,7 +727,7 @@ double rt_oracle_render(const rtx_scene_desc* s, const rtx_camera* cam, uint8_t*
     pthread_t* th = (pthread_t*)calloc((size_t)nthreads, sizeof(pthread_t));
     for (int i = 0; i < nthreads; i++) {
         jobs[i].s = s; jobs[i].cam = cam; jobs[i].rgb = rgb; jobs[i].hits = hits;
-        jobs[i].tid = i; jobs[i].nthreads = nthreads;
+        jobs[i].tid = i; jobs[i].nthreads = nthreads; jobs[i].consistent = consistent;
         if (nthreads > 1) pthread_create(&th[i], NULL, worker, &jobs[i]);
     }
     if (nthreads == 1) worker(&jobs[0]);
@@ -721,6 +743,17 @@ double rt_oracle_render(const rtx_scene_desc* s, const rtx_camera* cam, uint8_t*
     }
     free(jobs); free(th);
     return (t1.tv_sec - t0.tv_sec) * 1e3 + (t1.tv_nsec - t0.tv_nsec) * 1e-6;
+}
+
+double rt_oracle_render(const rtx_scene_desc* s, const rtx_camera* cam, uint8_t* rgb,
+                        rtx_hit_id* hits, rt_oracle_counters* counters, int nthreads) {
+    return render(s, cam, rgb, hits, counters, nthreads, 0);
+}
+
+/* The same for the device library's consistent mode (see ctx_t); not reference behaviour. */
+double rt_oracle_render_consistent(const rtx_scene_desc* s, const rtx_camera* cam, uint8_t* rgb,
+                                   rtx_hit_id* hits, rt_oracle_counters* counters, int nthreads) {
+    return render(s, cam, rgb, hits, counters, nthreads, 1);
 }
 
 int rt_oracle_abi_version(void) { return RTX_ABI_VERSION; }

@@ -161,6 +161,11 @@ class DeviceScene:
     def set_counters(self, enable: bool):
         self._lib.rtx_scene_set_counters(self._h, int(enable))
 
+    def set_consistent(self, enable: bool):
+        """Consistent mode (not the reference's results for scaled instances; see rtx_amd.h)."""
+        if self._lib.rtx_scene_set_consistent(self._h, int(enable)) != 0:
+            raise RtxError(self._lib.rtx_last_error().decode())
+
     def set_queue_limit(self, nbytes: int):
         self._lib.rtx_scene_set_queue_limit(self._h, int(nbytes))
 

@@ -69,6 +69,7 @@ struct rtx_scene {
     Scene dev{};                    // kernel argument (device pointers inside)
     int n_meshes = 0;
     bool counters_on = false;
+    bool consistent = false;
     int64_t queue_limit = (int64_t)32 << 30;
     uint32_t queue_capacity = 0;    // rays per queue, grows on overflow and is then kept
     DevBuf materials, lights, xforms, planes, spheres, ftris, meshes, insts, objs, blas, tri_vn;
@@ -594,6 +595,12 @@ int rtx_scene_set_counters(rtx_scene* sc, int32_t enable) {
     return RTX_OK;
 }
 
+int rtx_scene_set_consistent(rtx_scene* sc, int32_t enable) {
+    if (!sc) return fail(RTX_EINVAL, "null scene");
+    sc->consistent = enable != 0;
+    return RTX_OK;
+}
+
 int rtx_scene_set_queue_limit(rtx_scene* sc, int64_t bytes) {
     if (!sc || bytes < (int64_t)(1 << 20)) return fail(RTX_EINVAL, "bad queue limit");
     sc->queue_limit = bytes;
@@ -641,6 +648,7 @@ int rtx_render(rtx_scene* sc, const rtx_camera* cam, int32_t tw, int32_t th, int
     if (rc) return rc;
     const bool whole = (g.n_tiles == 1 && first == 0);
     if (hit_ids && !whole) return fail(RTX_EINVAL, "hit_ids are only available for whole-frame renders");
+    if (sc->counters_on && sc->consistent) return fail(RTX_EINVAL, "work counters are not available in consistent mode");
     if (stats) memset(stats, 0, sizeof *stats);
     if (g.n_sel == 0) return RTX_OK;
     HIP_TRY(hipSetDevice(sc->device));
@@ -764,25 +772,24 @@ int rtx_render(rtx_scene* sc, const rtx_camera* cam, int32_t tw, int32_t th, int
             sc->gen_events.push_back(e);
         }
         std::vector<hipEvent_t>& gev = sc->gen_events;
+        using TraceKernel = void (*)(const Launch*, GenCtrl*, int, double*, rtx_hit_id*, Counters*);
+        const TraceKernel trace_main =
+            sc->counters_on ? k_trace<true, 0, false>
+            : sc->consistent ? (launch.wide_old ? k_trace<false, 1, true> : k_trace<false, 0, true>)
+                             : (launch.wide_old ? k_trace<false, 1, false> : k_trace<false, 0, false>);
+        const TraceKernel trace_tiny = sc->consistent ? k_trace<false, 2, true> : k_trace<false, 2, false>;
         HIP_TRY(hipEventRecord(sc->ev0, sc->stream));
         for (int gen = 0; gen < G; gen++) {
             HIP_TRY(hipEventRecord(gev[2 * gen], sc->stream));
             unsigned blocks = persistent_blocks;
             if (gen == 0) blocks = (unsigned)std::min<int64_t>(persistent_blocks, (n_items0 + 255) / 256);
             rtx_hit_id* aov = (gen == 0 && hit_ids) ? (rtx_hit_id*)sc->aov.p : nullptr;
-            if (sc->counters_on)
-                hipLaunchKernelGGL((k_trace<true, 0>), dim3(blocks), dim3(256), 0, sc->stream, lp, (GenCtrl*)sc->ctrl.p, gen,
-                                   (double*)sc->accum.p, aov, (Counters*)sc->counters.p + gen);
-            else if (launch.wide_old)
-                hipLaunchKernelGGL((k_trace<false, 1>), dim3(blocks), dim3(256), 0, sc->stream, lp, (GenCtrl*)sc->ctrl.p, gen,
-                                   (double*)sc->accum.p, aov, (Counters*)nullptr);
-            else
-                hipLaunchKernelGGL((k_trace<false, 0>), dim3(blocks), dim3(256), 0, sc->stream, lp, (GenCtrl*)sc->ctrl.p, gen,
-                                   (double*)sc->accum.p, aov, (Counters*)nullptr);
+            hipLaunchKernelGGL(trace_main, dim3(blocks), dim3(256), 0, sc->stream, lp, (GenCtrl*)sc->ctrl.p, gen,
+                               (double*)sc->accum.p, aov, sc->counters_on ? (Counters*)sc->counters.p + gen : (Counters*)nullptr);
             HIP_TRY(hipEventRecord(gev[2 * gen + 1], sc->stream));
             // the variant for tiny generations (one of the two returns at once; see k_trace)
             if (!sc->counters_on && launch.wide_ok)
-                hipLaunchKernelGGL((k_trace<false, 2>), dim3(blocks), dim3(256), 0, sc->stream, lp, (GenCtrl*)sc->ctrl.p, gen,
+                hipLaunchKernelGGL(trace_tiny, dim3(blocks), dim3(256), 0, sc->stream, lp, (GenCtrl*)sc->ctrl.p, gen,
                                    (double*)sc->accum.p, aov, (Counters*)nullptr);
             // the last generation holds shadow rays only: nothing left to shade
             if (gen + 1 < G)

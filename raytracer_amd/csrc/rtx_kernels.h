@@ -497,8 +497,8 @@ struct RecOut {
 // A fresh ray: empty record, then the classes that come before the meshes
 // (planes, utils.cpp:683-685; free triangles, utils.cpp:692-729).
 template <bool COUNT>
-RTX_DEV void ray_begin(const Scene& S, Lane& L, const RecOut& out, Tally& tl) {
-    L.t_min = DBL_MAX;
+RTX_DEV void ray_begin(const Scene& S, Lane& L, const RecOut& out, const double bound0, Tally& tl) {
+    L.t_min = bound0;                 // DBL_MAX in the reference (utils.cpp:676)
     L.dist = 0.0;
     L.hit = 0;
     if (S.n_planes > 0 || S.n_ftris > 0) {
@@ -526,7 +526,7 @@ RTX_DEV void ray_begin(const Scene& S, Lane& L, const RecOut& out, Tally& tl) {
 // Advance the lane's object iterator until an object needs traversal (returns true, job set
 // up: rayHitsMesh's prologue, utils.cpp:418-494 + the root test of bvh.cpp:132) or the
 // object sequence is exhausted (returns false).
-template <bool COUNT>
+template <bool COUNT, bool FAST>
 RTX_DEV bool job_next(const Scene& S, Lane& L, const RecOut& out, unsigned* inst_bits, const double light_dist, Tally& tl) {
     const RTX_GLOBAL Obj* const objs = (const RTX_GLOBAL Obj*)S.objs;
     const unsigned n_summary = rtx_summary_words(S.n_insts);
@@ -605,6 +605,7 @@ RTX_DEV bool job_next(const Scene& S, Lane& L, const RecOut& out, unsigned* inst
         const int flags = __double2loint(ob2[13]);
         if (flags & OBJ_SKIP) continue;
         V3 ro = L.o, rd = L.d;
+        double bound = L.t_min;
         if (flags & OBJ_XF) {
             if (flags & OBJ_BOUNDS) {                                // utils.cpp:446-466, 760-766
                 if (COUNT) tl.world_box++;
@@ -620,15 +621,27 @@ RTX_DEV bool job_next(const Scene& S, Lane& L, const RecOut& out, unsigned* inst
             }
             ro = xf_point(inv, L.o);                                 // utils.cpp:481-489
             rd = normalize_f32(xf_dir(inv, L.d));
+            if (FAST) {
+                // consistent mode: the bound goes to object space with the ray (the divisor is the
+                // factor normalize_f32 applied to the direction)
+                const V3 od = xf_dir(inv, L.d);
+                bound = L.t_min / (1.0 / (double)sqrtf((float)(od.x * od.x + od.y * od.y + od.z * od.z)));
+            }
         }
         const Slab sl = make_slab(ro, rd);
         double enter;
-        if (!box_enter(ob2 + 6, ob2 + 9, sl, enter) || !(L.t_min >= enter)) continue;
+        if (!box_enter(ob2 + 6, ob2 + 9, sl, enter) || !(bound >= enter)) continue;
         L.obj = oi;
         L.orig_t_min = L.t_min;
+        if (FAST) L.t_min = bound;
         L.is_shadow &= 1;
         if (!COUNT) L.age = 0;       // (steps of the job; with counters on: of the ray, for the histogram)
-        if (!COUNT && L.is_shadow && !(flags & OBJ_XF)) {
+        if (FAST && L.is_shadow) {
+            // consistent mode: a shadow ray's bound starts at the light's distance, so the first
+            // accepted triangle of any job, transformed or not, decides it
+            L.is_shadow = 3;
+            L.orig_t_min = bound;
+        } else if (!COUNT && L.is_shadow && !(flags & OBJ_XF)) {
             // A shadow ray asks only whether something lies in front of the light
             // (utils.cpp:1066-1084: hit && distance < |L - P|).  Once a hit has been accepted
             // with the bound below that distance the answer is yes whatever follows: the bound
@@ -651,8 +664,12 @@ RTX_DEV bool job_next(const Scene& S, Lane& L, const RecOut& out, unsigned* inst
 // (utils.cpp:533-668), including the fields the winning triangle test wrote
 // (utils.cpp:370-381, bvh.cpp:162).  beta and gamma of the winning triangle are recomputed
 // here with the same arithmetic that accepted it (same inputs, same bits).
+template <bool FAST>
 RTX_DEV void job_finalize(const Scene& S, Lane& L, const RecOut& out) {
-    if (L.btri < 0) return;
+    if (L.btri < 0) {
+        if (FAST) L.t_min = L.orig_t_min;         // (a transformed job ran with the object-space bound)
+        return;
+    }
     const int tri = L.btri - S.tri_key0;             // triangle index (the traversal works with record keys)
     const RTX_GLOBAL Tri* Tg = (const RTX_GLOBAL Tri*)(S.blas + (size_t)(unsigned)L.btri * 128u);
     const RTX_GLOBAL Obj* ob = (const RTX_GLOBAL Obj*)S.objs + L.obj;
@@ -666,9 +683,12 @@ RTX_DEV void job_finalize(const Scene& S, Lane& L, const RecOut& out) {
     tri_test(T, L.ro, L.rd, INFINITY, S.isect_eps, t, beta, gamma);
     const V3 a = mk(T[0], T[1], T[2]), e1 = mk(T[3], T[4], T[5]), e2 = mk(T[6], T[7], T[8]);
     const V3 point = vadd(vadd(a, sscale(beta, e1)), sscale(gamma, e2));
-    out.bary(beta, gamma, face, tri);
-    out.kind(RTX_KIND_MESH);
+    if (!FAST) {
+        out.bary(beta, gamma, face, tri);
+        out.kind(RTX_KIND_MESH);
+    }
     if (!(flags & OBJ_XF)) {
+        if (FAST) { out.bary(beta, gamma, face, tri); out.kind(RTX_KIND_MESH); }
         out.geom(L.t_min, point, gn, gn);
         out.owner(mat, mi);
         out.src(L.obj);
@@ -681,6 +701,12 @@ RTX_DEV void job_finalize(const Scene& S, Lane& L, const RecOut& out) {
     V3 wp = xf_point(m, point);
     double dx = wp.x - L.o.x, dy = wp.y - L.o.y, dz = wp.z - L.o.z;
     double wd = (double)sqrtf((float)(dx * dx + dy * dy + dz * dz));
+    if (FAST) {
+        // consistent mode: a hit that is not nearer than the bound leaves no trace
+        if (wd >= L.orig_t_min) { L.t_min = L.orig_t_min; return; }
+        out.bary(beta, gamma, face, tri);
+        out.kind(RTX_KIND_MESH);
+    }
     if (wd >= L.orig_t_min) {             // utils.cpp:567-570: bound restored, record is not
         out.geom(L.t_min, point, gn, gn);
         out.owner(mat, mi);
@@ -873,7 +899,7 @@ RTX_DEV V3 primary_direction(const Frame& F, int px, int py) {
 
 // Divergent per-lane part of a service pass.  `fresh`: the lane has just been handed a new ray
 // (L.slot / L.o / L.d / L.is_shadow set).
-template <bool COUNT>
+template <bool COUNT, bool FAST>
 RTX_DEV void service_lane(const Launch* __restrict__ Lp, const int gen, double* __restrict__ accum,
                           rtx_hit_id* __restrict__ aov, Lane& L, unsigned* inst_bits, const bool fresh, Tally& tl) {
     const Scene& S = Lp->S;
@@ -885,7 +911,8 @@ RTX_DEV void service_lane(const Launch* __restrict__ Lp, const int gen, double* 
     long long c0 = COUNT ? clock64() : 0;
     if (fresh) {
         if (COUNT) { tl.rays++; if (gen == 0) tl.primary++; else if (L.is_shadow) tl.shadow++; else tl.secondary++; }
-        ray_begin<COUNT>(S, L, out, tl);
+        // consistent mode: a shadow ray looks no further than its light
+        ray_begin<COUNT>(S, L, out, FAST && L.is_shadow ? ((const RTX_GLOBAL Ray*)qin.rays + slot)->aux : DBL_MAX, tl);
         if (COUNT) { const long long c = clock64(); tl.sec[0] += (unsigned long long)(c - c0); tl.sec[4]++; c0 = c; }
     }
     if (L.state == LS_JOB_DONE) {
@@ -896,8 +923,12 @@ RTX_DEV void service_lane(const Launch* __restrict__ Lp, const int gen, double* 
             L.whi = L.whi < 0 ? -1 : (L.whi >> 5);
             L.bits = 0u; L.sbits = 0u;
             L.obj = -2;
+        } else if (FAST && L.is_shadow) {
+            // consistent mode: any accepted triangle occludes; the bound is the light's distance again
+            if (L.btri >= 0) L.hit = 1;
+            L.t_min = ((const RTX_GLOBAL Ray*)qin.rays + slot)->aux;
         } else {
-            job_finalize(S, L, out);
+            job_finalize<FAST>(S, L, out);
         }
         L.state = LS_NEED_JOB;
         if (COUNT) { const long long c = clock64(); tl.sec[1] += (unsigned long long)(c - c0); tl.sec[5]++; c0 = c; }
@@ -907,7 +938,7 @@ RTX_DEV void service_lane(const Launch* __restrict__ Lp, const int gen, double* 
     // lane's candidate bitmap must be clear when the next ray starts.
     double light_dist = 0.0;
     if (!COUNT && L.is_shadow) light_dist = ((const RTX_GLOBAL Ray*)qin.rays + slot)->aux;
-    const bool decided = !COUNT && L.is_shadow && L.hit != 0 && L.t_min < light_dist;
+    const bool decided = !COUNT && L.is_shadow && L.hit != 0 && (FAST || L.t_min < light_dist);
     if (decided && L.it > S.n_meshes) {
         // (the current word was cleared when it was taken; what is still set in memory: the
         // words flagged in the current summary word, and the summary words not yet taken)
@@ -926,14 +957,14 @@ RTX_DEV void service_lane(const Launch* __restrict__ Lp, const int gen, double* 
         }
         L.bits = 0u; L.sbits = 0u; L.sword = L.whi;
     }
-    const bool more = !decided && job_next<COUNT>(S, L, out, inst_bits, light_dist, tl);
+    const bool more = !decided && job_next<COUNT, FAST>(S, L, out, inst_bits, light_dist, tl);
     if (COUNT) { const long long c = clock64(); tl.sec[2] += (unsigned long long)(c - c0); tl.sec[6]++; c0 = c; }
     if (more) { L.state = LS_IN_JOB; return; }
     // ---- ray complete ------------------------------------------------------------------------
     const bool hit = L.hit != 0;
     if (L.is_shadow) {                                            // utils.cpp:1083
         const RTX_GLOBAL Ray* r = (const RTX_GLOBAL Ray*)qin.rays + slot;
-        if (!(hit && L.dist < r->aux)) add_color(accum, r->pixel, mk(r->w[0], r->w[1], r->w[2]));
+        if (!(hit && (FAST || L.dist < r->aux))) add_color(accum, r->pixel, mk(r->w[0], r->w[1], r->w[2]));
     } else {
         if (gen == 0 && aov != nullptr) {
             int px, py; unsigned pixel;
@@ -1450,7 +1481,7 @@ RTX_DEV unsigned long long traverse_steps(const Scene& S, const Wave& wv, Lane& 
 // WIDE = 0: main variant without any of it.  (Variants rather than branches: the mere presence
 // of the call changes the register allocation of the code around it -- the service passes pay
 // for it, which scenes dominated by instance replay notice -- so the host picks per scene.)
-template <bool COUNT, int WIDE>
+template <bool COUNT, int WIDE, bool FAST>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RTX_TRACE_WAVES, RTX_TRACE_WAVES)))
 k_trace(const Launch* __restrict__ Lp, GenCtrl* ctrl, const int gen, double* __restrict__ accum,
         rtx_hit_id* __restrict__ aov, Counters* __restrict__ counters) {
@@ -1548,7 +1579,7 @@ k_trace(const Launch* __restrict__ Lp, GenCtrl* ctrl, const int gen, double* __r
                     }
                 }
                 if (fresh || L.state == LS_JOB_DONE || L.state == LS_NEED_JOB)
-                    service_lane<COUNT>(Lp, gen, accum, aov, L, inst_bits, fresh, tl);
+                    service_lane<COUNT, FAST>(Lp, gen, accum, aov, L, inst_bits, fresh, tl);
                 if (drained || __ballot(L.state == LS_EMPTY) == 0ull) break;
             }
             if (COUNT) { tl.clk_serv += (unsigned long long)(clock64() - c0); tl.passes++; }

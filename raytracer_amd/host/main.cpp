@@ -2,13 +2,16 @@
 // that renders on the MI355X core instead of the CPU loops.
 //
 //   raytracer_amd <scene.json> [more.json ...] [-b [0|1]] [-m [0|1]] [-c [0|1]]
-//                 [--device D] [--shard R/N] [--out DIR] [--png] [--quiet] [--gpu-build]
+//                 [--device D] [--shard R/N] [--out DIR] [--png] [--quiet] [--gpu-build] [--consistent]
 //
 // -b  BVH on/off (default on; `-b` alone = on).  Off ships meshes without a BVH; the device
 //     then tests every face of a mesh in face order, like the reference's brute-force loop.
 // -m  accepted for compatibility (the reference's thread switch); it has no effect here.
 // -c  back-face culling (default off; `-c` alone = off, `-c 1` = on), as in the reference.
 // --gpu-build  build the meshes' BVHs on the device (rtx_build_bvh) instead of on the host.
+// --consistent  the core's consistent mode (rtx_scene_set_consistent): scaled instances are searched
+//     with the bound in object space, shadow rays end at their first hit.  Not the reference's
+//     pictures where a scene has scaled instances.
 // --shard R/N  render only scene files i with i % N == R (whole-frame sharding of an
 //     animation across N processes, one per GPU; no communication needed).
 //
@@ -107,7 +110,7 @@ private:
 
 int main(int argc, char** argv) {
     std::vector<std::string> scenes;
-    bool use_bvh = true, cull = false, multithreaded = true, png = false, quiet = false, gpu_build = false;
+    bool use_bvh = true, cull = false, multithreaded = true, png = false, quiet = false, gpu_build = false, consistent = false;
     int device = 0, shard_r = 0, shard_n = 1;
     std::string out_dir = "../my_outputs_hw2/";            // raytracer.cpp:13
     auto opt01 = [&](int& i, bool bare_value, bool& target) {
@@ -123,11 +126,12 @@ int main(int argc, char** argv) {
         else if (!strcmp(argv[i], "--shard") && i + 1 < argc) { if (sscanf(argv[++i], "%d/%d", &shard_r, &shard_n) != 2 || shard_n < 1 || shard_r < 0 || shard_r >= shard_n) { fprintf(stderr, "bad --shard\n"); return 2; } }
         else if (!strcmp(argv[i], "--png")) png = true;
         else if (!strcmp(argv[i], "--gpu-build")) gpu_build = true;
+        else if (!strcmp(argv[i], "--consistent")) consistent = true;
         else if (!strcmp(argv[i], "--quiet")) quiet = true;
         else scenes.push_back(argv[i]);
     }
     if (scenes.empty()) {
-        fprintf(stderr, "usage: raytracer_amd <scene.json>... [-b [0|1]] [-m [0|1]] [-c [0|1]] [--device D] [--shard R/N] [--out DIR] [--png] [--gpu-build]\n");
+        fprintf(stderr, "usage: raytracer_amd <scene.json>... [-b [0|1]] [-m [0|1]] [-c [0|1]] [--device D] [--shard R/N] [--out DIR] [--png] [--gpu-build] [--consistent]\n");
         return 2;
     }
     (void)multithreaded;
@@ -194,6 +198,7 @@ int main(int argc, char** argv) {
                 return 1;                                    // no device: nothing else can work either
             }
             upload_ms = std::chrono::duration<double, std::milli>(std::chrono::high_resolution_clock::now() - t0).count();
+            if (consistent) rtx_scene_set_consistent(ds, 1);
         }
         double total_ms = pre_ms;
         for (int k = 0; k < rtx_host_camera_count(hs); k++) {

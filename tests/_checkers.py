@@ -38,17 +38,20 @@ def oracle_lib():
         lib.rt_oracle_render.argtypes = [C.POINTER(_abi.SceneDesc), C.POINTER(_abi.Camera), C.c_void_p,
                                          C.c_void_p, C.POINTER(OracleCounters), C.c_int]
         lib.rt_oracle_render.restype = C.c_double
+        lib.rt_oracle_render_consistent.argtypes = lib.rt_oracle_render.argtypes
+        lib.rt_oracle_render_consistent.restype = C.c_double
         _oracle = lib
     return _oracle
 
 
-def oracle_render(desc, cam, want_hits=True, nthreads=8):
-    """-> (rgb uint8[h][w][3], hits structured array | None, counters dict, elapsed ms)"""
+def oracle_render(desc, cam, want_hits=True, nthreads=8, consistent=False):
+    """-> (rgb uint8[h][w][3], hits structured array | None, counters dict, elapsed ms)
+    consistent: the restatement of the device library's consistent mode instead of the reference's."""
     rgb = np.empty((cam.height, cam.width, 3), dtype=np.uint8)
     hits = np.empty(cam.height * cam.width, dtype=_abi.HIT_DTYPE) if want_hits else None
     ctr = OracleCounters()
-    ms = oracle_lib().rt_oracle_render(desc, C.byref(cam), rgb.ctypes.data,
-                                       hits.ctypes.data if want_hits else None, C.byref(ctr), nthreads)
+    fn = oracle_lib().rt_oracle_render_consistent if consistent else oracle_lib().rt_oracle_render
+    ms = fn(desc, C.byref(cam), rgb.ctypes.data, hits.ctypes.data if want_hits else None, C.byref(ctr), nthreads)
     if ms < 0:
         raise RuntimeError("rt_oracle_render rejected its arguments")
     return rgb, hits, ctr.as_dict(), ms
