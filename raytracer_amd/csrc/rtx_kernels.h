@@ -437,6 +437,9 @@ enum { LS_EMPTY = 0, LS_NEED_JOB = 1, LS_JOB_DONE = 2, LS_IN_JOB = 3 };
 #ifndef RTX_LINEAR_INSTS
 #define RTX_LINEAR_INSTS 4           // up to this many instances are tried one after the other, without a TLAS walk (< 32)
 #endif
+#ifndef RTX_LDS_OBJS
+#define RTX_LDS_OBJS 16              // object records (512 B each) kept in LDS per block: the first so many of the scene
+#endif
 #ifndef RTX_SCATTER0_SHIFT
 #define RTX_SCATTER0_SHIFT 6         // generation 0: whole 8x8 pixel blocks (64 items) are scattered
 #endif
@@ -496,6 +499,16 @@ struct RecOut {
 
 // A fresh ray: empty record, then the classes that come before the meshes
 // (planes, utils.cpp:683-685; free triangles, utils.cpp:692-729).
+// The scene's first object records, copied to LDS when the block starts.  A lane that moves on
+// to its next object reads the record in a chain of dependent loads (flags and boxes, then the
+// matrix, then the root); from LDS each link costs a fraction of a trip to L2.  Records beyond
+// the cached ones are read from memory (one pointer type serves both).
+struct ObjCache {
+    const Obj* lds;
+    int n;
+    RTX_DEV const Obj* at(const Scene& S, int oi) const { return oi < n ? lds + oi : S.objs + oi; }
+};
+
 template <bool COUNT>
 RTX_DEV void ray_begin(const Scene& S, Lane& L, const RecOut& out, const double bound0, Tally& tl) {
     L.t_min = bound0;                 // DBL_MAX in the reference (utils.cpp:676)
@@ -527,8 +540,7 @@ RTX_DEV void ray_begin(const Scene& S, Lane& L, const RecOut& out, const double 
 // up: rayHitsMesh's prologue, utils.cpp:418-494 + the root test of bvh.cpp:132) or the
 // object sequence is exhausted (returns false).
 template <bool COUNT, bool FAST>
-RTX_DEV bool job_next(const Scene& S, Lane& L, const RecOut& out, unsigned* inst_bits, const double light_dist, Tally& tl) {
-    const RTX_GLOBAL Obj* const objs = (const RTX_GLOBAL Obj*)S.objs;
+RTX_DEV bool job_next(const Scene& S, const ObjCache& oc, Lane& L, const RecOut& out, unsigned* inst_bits, const double light_dist, Tally& tl) {
     const unsigned n_summary = rtx_summary_words(S.n_insts);
     const Slab ws = make_slab(L.o, L.d);         // world-space slab constants, once per call
     while (true) {
@@ -594,10 +606,10 @@ RTX_DEV bool job_next(const Scene& S, Lane& L, const RecOut& out, unsigned* inst
             oi = S.n_meshes + idx;
         }
         // second 128 bytes of the object record in one batch: world box, root box, root, flags
-        const RTX_GLOBAL Obj* ob = objs + oi;
+        const Obj* ob = oc.at(S, oi);
         double ob2[16];
         {
-            const RTX_GLOBAL v2d* p2 = (const RTX_GLOBAL v2d*)ob->bmin;
+            const v2d* p2 = (const v2d*)ob->bmin;
 #pragma unroll
             for (int k = 0; k < 7; k++) { const v2d v = p2[k]; ob2[2 * k] = v.x; ob2[2 * k + 1] = v.y; }
         }
@@ -615,7 +627,7 @@ RTX_DEV bool job_next(const Scene& S, Lane& L, const RecOut& out, unsigned* inst
             if (COUNT) tl.obj_trav++;
             double inv[16];
             {
-                const RTX_GLOBAL v2d* p1 = (const RTX_GLOBAL v2d*)ob->inv;
+                const v2d* p1 = (const v2d*)ob->inv;
 #pragma unroll
                 for (int k = 0; k < 8; k++) { const v2d v = p1[k]; inv[2 * k] = v.x; inv[2 * k + 1] = v.y; }
             }
@@ -665,14 +677,14 @@ RTX_DEV bool job_next(const Scene& S, Lane& L, const RecOut& out, unsigned* inst
 // (utils.cpp:370-381, bvh.cpp:162).  beta and gamma of the winning triangle are recomputed
 // here with the same arithmetic that accepted it (same inputs, same bits).
 template <bool FAST>
-RTX_DEV void job_finalize(const Scene& S, Lane& L, const RecOut& out) {
+RTX_DEV void job_finalize(const Scene& S, const ObjCache& oc, Lane& L, const RecOut& out) {
     if (L.btri < 0) {
         if (FAST) L.t_min = L.orig_t_min;         // (a transformed job ran with the object-space bound)
         return;
     }
     const int tri = L.btri - S.tri_key0;             // triangle index (the traversal works with record keys)
     const RTX_GLOBAL Tri* Tg = (const RTX_GLOBAL Tri*)(S.blas + (size_t)(unsigned)L.btri * 128u);
-    const RTX_GLOBAL Obj* ob = (const RTX_GLOBAL Obj*)S.objs + L.obj;
+    const Obj* ob = oc.at(S, L.obj);
     double T[9];
 #pragma unroll
     for (int k = 0; k < 3; k++) { T[k] = Tg->a[k]; T[3 + k] = Tg->e1[k]; T[6 + k] = Tg->e2[k]; }
@@ -900,7 +912,7 @@ RTX_DEV V3 primary_direction(const Frame& F, int px, int py) {
 // Divergent per-lane part of a service pass.  `fresh`: the lane has just been handed a new ray
 // (L.slot / L.o / L.d / L.is_shadow set).
 template <bool COUNT, bool FAST>
-RTX_DEV void service_lane(const Launch* __restrict__ Lp, const int gen, double* __restrict__ accum,
+RTX_DEV void service_lane(const Launch* __restrict__ Lp, const ObjCache& oc, const int gen, double* __restrict__ accum,
                           rtx_hit_id* __restrict__ aov, Lane& L, unsigned* inst_bits, const bool fresh, Tally& tl) {
     const Scene& S = Lp->S;
     const Frame& F = Lp->F;
@@ -928,7 +940,7 @@ RTX_DEV void service_lane(const Launch* __restrict__ Lp, const int gen, double* 
             if (L.btri >= 0) L.hit = 1;
             L.t_min = ((const RTX_GLOBAL Ray*)qin.rays + slot)->aux;
         } else {
-            job_finalize<FAST>(S, L, out);
+            job_finalize<FAST>(S, oc, L, out);
         }
         L.state = LS_NEED_JOB;
         if (COUNT) { const long long c = clock64(); tl.sec[1] += (unsigned long long)(c - c0); tl.sec[5]++; c0 = c; }
@@ -957,7 +969,7 @@ RTX_DEV void service_lane(const Launch* __restrict__ Lp, const int gen, double* 
         }
         L.bits = 0u; L.sbits = 0u; L.sword = L.whi;
     }
-    const bool more = !decided && job_next<COUNT, FAST>(S, L, out, inst_bits, light_dist, tl);
+    const bool more = !decided && job_next<COUNT, FAST>(S, oc, L, out, inst_bits, light_dist, tl);
     if (COUNT) { const long long c = clock64(); tl.sec[2] += (unsigned long long)(c - c0); tl.sec[6]++; c0 = c; }
     if (more) { L.state = LS_IN_JOB; return; }
     // ---- ray complete ------------------------------------------------------------------------
@@ -1503,6 +1515,13 @@ k_trace(const Launch* __restrict__ Lp, GenCtrl* ctrl, const int gen, double* __r
         const bool tiny = Lp->wide_ok != 0 && n_in <= RTX_WIDE_MAX_RAYS;
         if (tiny != (WIDE == 2)) return;
     }
+    __shared__ __attribute__((aligned(16))) double lds_objs[RTX_LDS_OBJS * (sizeof(Obj) / 8)];
+    ObjCache oc;
+    oc.lds = (const Obj*)lds_objs;
+    oc.n = min(S.n_meshes + S.n_insts, RTX_LDS_OBJS);
+    for (unsigned i = threadIdx.x; i < (unsigned)oc.n * (unsigned)(sizeof(Obj) / 16); i += blockDim.x)
+        ((v2d*)lds_objs)[i] = ((const RTX_GLOBAL v2d*)S.objs)[i];
+    __syncthreads();
     Tally tl = {};
     const long long clk_begin = COUNT ? clock64() : 0;
 
@@ -1579,7 +1598,7 @@ k_trace(const Launch* __restrict__ Lp, GenCtrl* ctrl, const int gen, double* __r
                     }
                 }
                 if (fresh || L.state == LS_JOB_DONE || L.state == LS_NEED_JOB)
-                    service_lane<COUNT, FAST>(Lp, gen, accum, aov, L, inst_bits, fresh, tl);
+                    service_lane<COUNT, FAST>(Lp, oc, gen, accum, aov, L, inst_bits, fresh, tl);
                 if (drained || __ballot(L.state == LS_EMPTY) == 0ull) break;
             }
             if (COUNT) { tl.clk_serv += (unsigned long long)(clock64() - c0); tl.passes++; }
