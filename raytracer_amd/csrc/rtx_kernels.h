@@ -438,7 +438,7 @@ enum { LS_EMPTY = 0, LS_NEED_JOB = 1, LS_JOB_DONE = 2, LS_IN_JOB = 3 };
 #define RTX_LINEAR_INSTS 4           // up to this many instances are tried one after the other, without a TLAS walk (< 32)
 #endif
 #ifndef RTX_LDS_OBJS
-#define RTX_LDS_OBJS 16              // object records (512 B each) kept in LDS per block: the first so many of the scene
+#define RTX_LDS_OBJS 12              // object records (512 B each) kept in LDS per block: the first so many of the scene
 #endif
 #ifndef RTX_SCATTER0_SHIFT
 #define RTX_SCATTER0_SHIFT 6         // generation 0: whole 8x8 pixel blocks (64 items) are scattered
@@ -503,9 +503,13 @@ struct RecOut {
 // to its next object reads the record in a chain of dependent loads (flags and boxes, then the
 // matrix, then the root); from LDS each link costs a fraction of a trip to L2.  Records beyond
 // the cached ones are read from memory (one pointer type serves both).
+// ctx: five doubles of LDS per lane for what a shadow ray needs again after its traversal --
+// its light's distance (at every change of object) and, if it ends unoccluded, pixel and
+// weight -- taken from the ray record together with origin and direction, in the same trip.
 struct ObjCache {
     const Obj* lds;
     int n;
+    double* ctx;          // [0] light distance, [1..3] weight, [4] pixel (low word)
     RTX_DEV const Obj* at(const Scene& S, int oi) const { return oi < n ? lds + oi : S.objs + oi; }
 };
 
@@ -685,6 +689,11 @@ RTX_DEV void job_finalize(const Scene& S, const ObjCache& oc, Lane& L, const Rec
     const int tri = L.btri - S.tri_key0;             // triangle index (the traversal works with record keys)
     const RTX_GLOBAL Tri* Tg = (const RTX_GLOBAL Tri*)(S.blas + (size_t)(unsigned)L.btri * 128u);
     const Obj* ob = oc.at(S, L.obj);
+    if (!out.on && !(ob->flags & OBJ_XF)) {
+        // a shadow ray keeps no record: of an untransformed hit only distance and flag remain
+        L.dist = L.t_min; L.hit = 1;
+        return;
+    }
     double T[9];
 #pragma unroll
     for (int k = 0; k < 3; k++) { T[k] = Tg->a[k]; T[3 + k] = Tg->e1[k]; T[6 + k] = Tg->e2[k]; }
@@ -726,6 +735,7 @@ RTX_DEV void job_finalize(const Scene& S, const ObjCache& oc, Lane& L, const Rec
         L.t_min = L.orig_t_min;
         return;
     }
+    if (!out.on) { L.dist = wd; L.t_min = wd; L.hit = 1; return; }      // (shadow ray: no record)
     double nrm[12];
 #pragma unroll
     for (int k = 0; k < 12; k++) nrm[k] = ob->nrm[k];
@@ -924,7 +934,7 @@ RTX_DEV void service_lane(const Launch* __restrict__ Lp, const ObjCache& oc, con
     if (fresh) {
         if (COUNT) { tl.rays++; if (gen == 0) tl.primary++; else if (L.is_shadow) tl.shadow++; else tl.secondary++; }
         // consistent mode: a shadow ray looks no further than its light
-        ray_begin<COUNT>(S, L, out, FAST && L.is_shadow ? ((const RTX_GLOBAL Ray*)qin.rays + slot)->aux : DBL_MAX, tl);
+        ray_begin<COUNT>(S, L, out, FAST && L.is_shadow ? oc.ctx[0] : DBL_MAX, tl);
         if (COUNT) { const long long c = clock64(); tl.sec[0] += (unsigned long long)(c - c0); tl.sec[4]++; c0 = c; }
     }
     if (L.state == LS_JOB_DONE) {
@@ -938,7 +948,7 @@ RTX_DEV void service_lane(const Launch* __restrict__ Lp, const ObjCache& oc, con
         } else if (FAST && L.is_shadow) {
             // consistent mode: any accepted triangle occludes; the bound is the light's distance again
             if (L.btri >= 0) L.hit = 1;
-            L.t_min = ((const RTX_GLOBAL Ray*)qin.rays + slot)->aux;
+            L.t_min = oc.ctx[0];
         } else {
             job_finalize<FAST>(S, oc, L, out);
         }
@@ -949,7 +959,7 @@ RTX_DEV void service_lane(const Launch* __restrict__ Lp, const ObjCache& oc, con
     // retired here.  Instance candidates it has collected but not replayed are dropped: the
     // lane's candidate bitmap must be clear when the next ray starts.
     double light_dist = 0.0;
-    if (!COUNT && L.is_shadow) light_dist = ((const RTX_GLOBAL Ray*)qin.rays + slot)->aux;
+    if (!COUNT && L.is_shadow) light_dist = oc.ctx[0];
     const bool decided = !COUNT && L.is_shadow && L.hit != 0 && (FAST || L.t_min < light_dist);
     if (decided && L.it > S.n_meshes) {
         // (the current word was cleared when it was taken; what is still set in memory: the
@@ -975,8 +985,8 @@ RTX_DEV void service_lane(const Launch* __restrict__ Lp, const ObjCache& oc, con
     // ---- ray complete ------------------------------------------------------------------------
     const bool hit = L.hit != 0;
     if (L.is_shadow) {                                            // utils.cpp:1083
-        const RTX_GLOBAL Ray* r = (const RTX_GLOBAL Ray*)qin.rays + slot;
-        if (!(hit && (FAST || L.dist < r->aux))) add_color(accum, r->pixel, mk(r->w[0], r->w[1], r->w[2]));
+        if (!(hit && (FAST || L.dist < oc.ctx[0])))
+            add_color(accum, (unsigned)__double2loint(oc.ctx[4]), mk(oc.ctx[1], oc.ctx[2], oc.ctx[3]));
     } else {
         if (gen == 0 && aov != nullptr) {
             int px, py; unsigned pixel;
@@ -1519,6 +1529,8 @@ k_trace(const Launch* __restrict__ Lp, GenCtrl* ctrl, const int gen, double* __r
     ObjCache oc;
     oc.lds = (const Obj*)lds_objs;
     oc.n = min(S.n_meshes + S.n_insts, RTX_LDS_OBJS);
+    __shared__ double lds_ctx[256 * 5];
+    oc.ctx = lds_ctx + threadIdx.x * 5;
     for (unsigned i = threadIdx.x; i < (unsigned)oc.n * (unsigned)(sizeof(Obj) / 16); i += blockDim.x)
         ((v2d*)lds_objs)[i] = ((const RTX_GLOBAL v2d*)S.objs)[i];
     __syncthreads();
@@ -1591,6 +1603,10 @@ k_trace(const Launch* __restrict__ Lp, GenCtrl* ctrl, const int gen, double* __r
                                 const RTX_GLOBAL Ray* r = (const RTX_GLOBAL Ray*)qin.rays + L.slot;
                                 L.o = mk(r->o[0], r->o[1], r->o[2]);
                                 L.d = mk(r->d[0], r->d[1], r->d[2]);
+                                if (sh) {
+                                    oc.ctx[0] = r->aux; oc.ctx[1] = r->w[0]; oc.ctx[2] = r->w[1]; oc.ctx[3] = r->w[2];
+                                    oc.ctx[4] = __hiloint2double(0, (int)r->pixel);
+                                }
                                 fresh = true;
                             }
                         }
