@@ -437,6 +437,12 @@ enum { LS_EMPTY = 0, LS_NEED_JOB = 1, LS_JOB_DONE = 2, LS_IN_JOB = 3 };
 #ifndef RTX_LINEAR_INSTS
 #define RTX_LINEAR_INSTS 4           // up to this many instances are tried one after the other, without a TLAS walk (< 32)
 #endif
+#ifndef RTX_SCATTER_THIN_RAYS
+#define RTX_SCATTER_THIN_RAYS (1u << 19)   // generations of fewer rays are scattered in finer groups:
+#endif
+#ifndef RTX_SCATTER_SHIFT_THIN
+#define RTX_SCATTER_SHIFT_THIN 0           // log2 of their group size
+#endif
 #ifndef RTX_LDS_OBJS
 #define RTX_LDS_OBJS 12              // object records (512 B each) kept in LDS per block: the first so many of the scene
 #endif
@@ -644,7 +650,8 @@ RTX_DEV bool job_next(const Scene& S, const ObjCache& oc, Lane& L, const RecOut&
                 bound = L.t_min / (1.0 / (double)sqrtf((float)(od.x * od.x + od.y * od.y + od.z * od.z)));
             }
         }
-        const Slab sl = make_slab(ro, rd);
+        // (an untransformed object is met by the world-space ray: same constants, no second set of divisions)
+        const Slab sl = (flags & OBJ_XF) ? make_slab(ro, rd) : ws;
         double enter;
         if (!box_enter(ob2 + 6, ob2 + 9, sl, enter) || !(bound >= enter)) continue;
         L.obj = oi;
@@ -832,7 +839,7 @@ RTX_DEV void emit(const Queue& q, GenCtrl* next, unsigned sub, bool shadow, bool
 struct GenItems {
     unsigned rad_end[RTX_NSUB], sh_end[RTX_NSUB];     // cumulative counts through sub-queue q
     unsigned n_rad, n_in, sub_capacity;
-    unsigned grp_r, grp_s, mul_r, mul_s;
+    unsigned grp_r, grp_s, mul_r, mul_s, shift;
 
     RTX_DEV void load(const GenCtrl* me, unsigned sub_cap) {
         sub_capacity = sub_cap;
@@ -848,7 +855,10 @@ struct GenItems {
         }
         n_rad = r_acc; n_in = r_acc + s_acc;
         // scattered hand-out order (see slot): multipliers coprime to the group counts
-        grp_r = n_rad >> RTX_SCATTER_SHIFT; grp_s = (n_in - n_rad) >> RTX_SCATTER_SHIFT;
+        // (a thin generation lasts as long as the wave that got most of its long rays, and rays
+        // emitted together are long together: there the groups are single rays)
+        shift = n_in < RTX_SCATTER_THIN_RAYS ? RTX_SCATTER_SHIFT_THIN : RTX_SCATTER_SHIFT;
+        grp_r = n_rad >> shift; grp_s = (n_in - n_rad) >> shift;
         mul_r = coprime_near_golden(grp_r); mul_s = coprime_near_golden(grp_s);
     }
     RTX_DEV static unsigned coprime_near_golden(unsigned n) {
@@ -871,8 +881,8 @@ struct GenItems {
         unsigned v = is_shadow ? w - n_rad : w;
         {
             const unsigned grp = is_shadow ? grp_s : grp_r, mul = is_shadow ? mul_s : mul_r;
-            const unsigned g = v >> RTX_SCATTER_SHIFT;
-            if (g < grp) v = (unsigned)(((unsigned long long)g * mul) % grp) << RTX_SCATTER_SHIFT | (v & ((1u << RTX_SCATTER_SHIFT) - 1u));
+            const unsigned g = v >> shift;
+            if (g < grp) v = (unsigned)(((unsigned long long)g * mul) % grp) << shift | (v & ((1u << shift) - 1u));
         }
         unsigned q = 0, prev = 0;
 #pragma unroll
@@ -1077,6 +1087,12 @@ RTX_DEV void cand_swap(Cand& a, Cand& b, bool doit) {
 #endif
 #ifndef RTX_WIDE_MAX_RAYS
 #define RTX_WIDE_MAX_RAYS 512        // generations with at most this many rays use it
+#endif
+#ifndef RTX_WIDE_LANES_THIN
+#define RTX_WIDE_LANES_THIN 6        // the two thresholds in generations below RTX_SCATTER_THIN_RAYS rays
+#endif
+#ifndef RTX_WIDE_AGE_THIN
+#define RTX_WIDE_AGE_THIN 32
 #endif
 #ifndef RTX_WIDE_AGE
 #define RTX_WIDE_AGE 32              // in a generation of size: only jobs that have taken this many steps already
@@ -1311,7 +1327,7 @@ RTX_DEV void wide_jobs(const Scene& S, const Wave& wv, Lane& L, glob_v4i* stk, u
 
 template <bool COUNT, int WIDE>
 RTX_DEV unsigned long long traverse_steps(const Scene& S, const Wave& wv, Lane& L, glob_v4i* __restrict__ stk, unsigned* inst_bits,
-                            const int service_threshold, const bool refillable, Tally& tl) {
+                            const int service_threshold, const bool refillable, const int wide_lanes, const int wide_age, Tally& tl) {
     const unsigned lane = wv.lane;
     const unsigned n_summary = rtx_summary_words(S.n_insts);
     const char* const blas = S.blas;
@@ -1329,8 +1345,8 @@ RTX_DEV unsigned long long traverse_steps(const Scene& S, const Wave& wv, Lane& 
                                                    (refillable && L.state == LS_EMPTY));
         if (__popcll(m_wait) >= service_threshold) break;
         // the generation has drained and this wave holds its last few jobs: the caller finishes them wave-wide
-        if (!COUNT && WIDE != 0 && !refillable && __popcll(m_job) <= RTX_WIDE_LANES) {
-            const unsigned long long m_old = WIDE == 2 ? m_job : __ballot(in_job && L.age >= RTX_WIDE_AGE);
+        if (!COUNT && WIDE != 0 && !refillable && __popcll(m_job) <= wide_lanes) {
+            const unsigned long long m_old = WIDE == 2 ? m_job : __ballot(in_job && L.age >= wide_age);
             if (m_old != 0ull) return m_old;
         }
         if (COUNT) {
@@ -1552,6 +1568,8 @@ k_trace(const Launch* __restrict__ Lp, GenCtrl* ctrl, const int gen, double* __r
                           ((size_t)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 64u + lane) * RTX_STACK;
     unsigned* const inst_bits = Lp->inst_bits + ((size_t)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 64u + lane) * Lp->inst_words;
     const int service_threshold = (int)Lp->service_threshold;
+    const bool thin = gen != 0 && n_in < RTX_SCATTER_THIN_RAYS;
+    const int wide_lanes = thin ? RTX_WIDE_LANES_THIN : RTX_WIDE_LANES, wide_age = thin ? RTX_WIDE_AGE_THIN : RTX_WIDE_AGE;
     Lane L;
     L.state = LS_EMPTY; L.cur_cnt = 0; L.cur_ref = 0; L.sp = 0; L.slot = 0; L.is_shadow = 0; L.btri = -1; L.obj = 0;
     L.top = (v4i)(0); L.t_min = 0.0; L.ro = mk(0, 0, 0); L.rd = mk(0, 0, 1); L.ix = L.iy = L.iz = 0.0; L.par = 0;
@@ -1622,7 +1640,7 @@ k_trace(const Launch* __restrict__ Lp, GenCtrl* ctrl, const int gen, double* __r
         }
         if (m_trav == 0ull) break;
         const long long c1 = COUNT ? clock64() : 0;
-        const unsigned long long m_wide = traverse_steps<COUNT, WIDE>(S, wv, L, stk, inst_bits, service_threshold, !drained, tl);
+        const unsigned long long m_wide = traverse_steps<COUNT, WIDE>(S, wv, L, stk, inst_bits, service_threshold, !drained, wide_lanes, wide_age, tl);
         if (!COUNT && WIDE != 0 && m_wide != 0ull) wide_jobs(S, wv, L, stk, inst_bits, Lp->inst_words, m_wide);
         if (COUNT) tl.clk_trav += (unsigned long long)(clock64() - c1);
     }
