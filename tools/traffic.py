@@ -9,9 +9,9 @@ tot = {"FETCH_SIZE": 0.0, "WRITE_SIZE": 0.0}
 n = {"FETCH_SIZE": set(), "WRITE_SIZE": set()}
 for f in sorted(glob.glob(d + "/*counter_collection.csv")):
     for r in csv.DictReader(open(f)):
-        # the main variant of the trace kernel (k_trace<false, 0> or <false, 1>), not the tiny-generation one
+        # the main variant of the trace kernel (k_trace<false, 0, ...> or <false, 1, ...>), not the tiny-generation one
         name = r["Kernel_Name"].replace(" ", "")
-        if not ("k_trace<false,0>" in name or "k_trace<false,1>" in name) or r["Counter_Name"] not in tot:
+        if not ("k_trace<false,0" in name or "k_trace<false,1" in name) or r["Counter_Name"] not in tot:
             continue
         tot[r["Counter_Name"]] += float(r["Counter_Value"])
         n[r["Counter_Name"]].add((f, r["Dispatch_Id"]))
