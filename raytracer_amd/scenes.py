@@ -527,5 +527,110 @@ UNIT_SCENES = {
 }
 
 
+def scene_random(out_dir, seed, res=(56, 40)):
+    """Seeded random scene for fuzzing the hot path against its checkers: a ground quad, 1-4
+    small bumpy meshes (flat or smooth, some with transforms of their own), 0-30 instances
+    (of meshes and of other instances, with and without ``_resetTransform``, scales below and
+    above one, mirrored ones), up to two spheres, sometimes a plane and a free triangle, 1-3
+    lights, every material type, recursion depth 0-4."""
+    rng = np.random.default_rng(10_000 + seed)
+    name = f"random_{seed:03d}"
+    verts = [(-25.0, 0.0, 25.0), (25.0, 0.0, 25.0), (25.0, 0.0, -25.0), (-25.0, 0.0, -25.0)]
+    mats = [_mat(1, (1, 1, 1), (0.55, 0.5, 0.45), (0.3, 0.3, 0.3), phong=12),
+            _mat(2, (0.2, 0.2, 0.2), (0.1, 0.1, 0.1), (0.5, 0.5, 0.5), phong=80, mirror=(0.8, 0.8, 0.8), mtype="mirror"),
+            _mat(3, (0, 0, 0), (0, 0, 0), (0, 0, 0), phong=60, mirror=(0.95, 0.7, 0.3), mtype="conductor", n=0.37, k=2.82),
+            _mat(4, (0, 0, 0), (0, 0, 0), (0, 0, 0), mtype="dielectric", n=1.5, sigma=(0.05, 0.1, 0.02)),
+            _mat(5, (1, 1, 1), (0.1, 0.6, 0.2), (0.4, 0.4, 0.4), phong=8),
+            _mat(6, (1, 1, 1), (0.7, 0.2, 0.2), (0.1, 0.1, 0.1), phong=3, mirror=(0.25, 0.25, 0.25))]
+    trans, scal, rots = [], [], []
+
+    def new_transform():
+        """A random chain 'sK rK tK' (parts optional) -> its reference string."""
+        parts = []
+        if rng.random() < 0.7:
+            k = rng.choice([0.3, 0.6, 1.0, 1.5, 2.2])
+            sx, sy, sz = (k, k, k) if rng.random() < 0.6 else tuple(k * rng.uniform(0.6, 1.4, size=3))
+            if rng.random() < 0.2:
+                sx = -sx
+            scal.append({"_id": str(len(scal) + 1), "_data": _s(float(sx), float(sy), float(sz))})
+            parts.append(f"s{len(scal)}")
+        if rng.random() < 0.6:
+            ax = rng.normal(size=3)
+            ax /= np.linalg.norm(ax)
+            rots.append({"_id": str(len(rots) + 1), "_data": _s(float(rng.uniform(-180, 180)), *map(float, ax))})
+            parts.append(f"r{len(rots)}")
+        trans.append({"_id": str(len(trans) + 1),
+                      "_data": _s(float(rng.uniform(-6, 6)), float(rng.uniform(-0.5, 2.5)), float(rng.uniform(-6, 4)))})
+        parts.append(f"t{len(trans)}")
+        return " ".join(parts)
+
+    meshes = [{"_id": "1", "Material": "1", "_shadingMode": "flat", "Faces": {"_data": "1 2 3 1 3 4"}}]
+    next_id = 2
+    n_base = int(rng.integers(1, 5))
+    for b in range(n_base):
+        v, f = bumpy_sphere(int(rng.integers(6, 14)), int(rng.integers(4, 9)), radius=float(rng.uniform(0.5, 1.3)),
+                            bump=0.25, seed=int(rng.integers(1 << 30)),
+                            center=(float(rng.uniform(-4, 4)), float(rng.uniform(0.6, 1.6)), float(rng.uniform(-4, 3))))
+        base = len(verts)
+        verts += [tuple(map(float, x)) for x in v]
+        m = {"_id": str(next_id), "Material": str(int(rng.integers(1, 7))),
+             "_shadingMode": "smooth" if rng.random() < 0.5 else "flat",
+             "Faces": {"_data": _flat(f + base + 1)}}
+        if rng.random() < 0.4:
+            m["Transformations"] = new_transform()
+        meshes.append(m)
+        next_id += 1
+    base_ids = [int(m["_id"]) for m in meshes[1:]]
+    insts = []
+    for _ in range(int(rng.choice([0, 1, 3, 4, 5, 9, 14, 30]))):
+        inst = {"_id": str(next_id), "_baseMeshId": str(int(rng.choice(base_ids))),
+                "_resetTransform": "true" if rng.random() < 0.6 else "false", "Transformations": new_transform()}
+        if rng.random() < 0.7:
+            inst["Material"] = str(int(rng.integers(1, 7)))
+        insts.append(inst)
+        if rng.random() < 0.3:
+            base_ids.append(next_id)                       # later instances may instance this one
+        next_id += 1
+    objects = {"Mesh": meshes}
+    if insts:
+        objects["MeshInstance"] = insts
+    spheres = []
+    for _ in range(int(rng.integers(0, 3))):
+        verts.append((float(rng.uniform(-4, 4)), float(rng.uniform(0.5, 2)), float(rng.uniform(-3, 4))))
+        sp = {"_id": str(next_id), "Material": str(int(rng.integers(1, 7))), "Center": str(len(verts)),
+              "Radius": _s(float(rng.uniform(0.4, 1.1)))}
+        if rng.random() < 0.4:
+            sp["Transformations"] = new_transform()
+        spheres.append(sp)
+        next_id += 1
+    if spheres:
+        objects["Sphere"] = spheres
+    if rng.random() < 0.3:
+        verts.append((0.0, 0.0, -9.0))
+        objects["Plane"] = [{"_id": str(next_id), "Material": "1", "Point": str(len(verts)), "Normal": "0 0 1"}]
+        next_id += 1
+    if rng.random() < 0.4:
+        verts += [(-3.0, 0.01, 2.5), (-1.0, 0.01, 2.5), (-2.0, 2.0, 2.0)]
+        tri = {"_id": str(next_id), "Material": str(int(rng.integers(1, 7))),
+               "Indices": f"{len(verts) - 2} {len(verts) - 1} {len(verts)}"}
+        if rng.random() < 0.5:
+            tri["Transformations"] = new_transform()
+        objects["Triangle"] = [tri]
+        next_id += 1
+    lights = [_light(k + 1, (float(rng.uniform(-9, 9)), float(rng.uniform(5, 11)), float(rng.uniform(-4, 9))),
+                     tuple(float(x) for x in rng.uniform(8000, 26000, size=3))) for k in range(int(rng.integers(1, 4)))]
+    sc = {
+        "BackgroundColor": "12 18 30", "MaxRecursionDepth": str(int(rng.integers(0, 5))), "ShadowRayEpsilon": "1e-3",
+        "IntersectionTestEpsilon": "1e-6",
+        "Cameras": {"Camera": _camera((float(rng.uniform(-3, 3)), float(rng.uniform(2, 6)), float(rng.uniform(9, 13))),
+                                      (0.0, 0.8, 0.0), (0, 1, 0), 42, res, name + ".png")},
+        "Lights": {"AmbientLight": "20 20 20", "PointLight": lights},
+        "Materials": {"Material": mats},
+        "Transformations": {k: v for k, v in (("Translation", trans), ("Scaling", scal), ("Rotation", rots)) if v},
+        "VertexData": {"_data": _flat(np.array(verts, dtype=np.float64))},
+        "Objects": objects}
+    return _dump(os.path.join(out_dir, name + ".json"), sc)
+
+
 def write_unit_scenes(out_dir):
     return {k: fn(out_dir) for k, fn in UNIT_SCENES.items()}

@@ -1,0 +1,32 @@
+"""Seeded random scenes (scenes.scene_random): the CPU restatement against the compiled
+reference, where that is present.  Image bytes and primary-hit records must be equal, with and
+without back-face culling."""
+import numpy as np
+import pytest
+
+import _checkers as ck
+import raytracer_amd as rt
+from raytracer_amd import scenes
+
+SEEDS = list(range(32))
+
+
+@pytest.mark.skipif(not ck.have_reference(), reason="compiled reference (oracle/_ref) not present")
+@pytest.mark.parametrize("seed", SEEDS)
+def test_oracle_equals_reference_on_random_scene(tmp_path, seed):
+    path = scenes.scene_random(str(tmp_path), seed)
+    for cull in (False, True):
+        prefix = str(tmp_path / f"ref{int(cull)}")
+        ck.reference_dump(path, prefix, cull=cull)
+        hs = rt.HostScene(path, True, cull)
+        cam, _ = hs.camera(0)
+        rgb, hits, _, _ = ck.oracle_render(hs.desc, cam)
+        assert np.array_equal(rgb, ck.read_rgb(prefix + ".cam0.rgb", cam.width, cam.height)), (seed, cull)
+        assert len(ck.compare_hits(hits, ck.read_hits(prefix + ".cam0.hits"))) == 0, (seed, cull)
+        hs.close()
+
+
+def test_random_scenes_are_deterministic(tmp_path):
+    a = open(scenes.scene_random(str(tmp_path / "a"), 5)).read()
+    b = open(scenes.scene_random(str(tmp_path / "b"), 5)).read()
+    assert a == b and a != open(scenes.scene_random(str(tmp_path / "c"), 6)).read()

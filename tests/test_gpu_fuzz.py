@@ -1,0 +1,39 @@
+"""Seeded random scenes (scenes.scene_random) on the GPU: the HIP core against the CPU
+restatement in its three modes -- counters on (every test of the reference carried out), the
+default mode, and the consistent mode against its own checker."""
+import numpy as np
+import pytest
+
+import _checkers as ck
+import raytracer_amd as rt
+from raytracer_amd import scenes
+
+pytestmark = pytest.mark.gpu
+
+SEEDS = list(range(64))
+
+
+@pytest.mark.parametrize("seed", SEEDS)
+def test_random_scene_matches_oracle(tmp_path, seed):
+    path = scenes.scene_random(str(tmp_path), seed)
+    cull = bool(seed & 1)
+    hs = rt.HostScene(path, True, cull)
+    ds = rt.DeviceScene(hs.desc, 0)
+    cam, _ = hs.camera(0)
+    o_rgb, o_hits, o_ctr, _ = ck.oracle_render(hs.desc, cam)
+    for counters in (True, False):
+        ds.set_counters(counters)
+        rgb, hits, st = ds.render(cam, want_hits=True)
+        bad = ck.compare_hits(hits, o_hits, allow_src_unknown=False)
+        assert len(bad) == 0, (seed, counters, bad[:5], hits[bad[:3]], o_hits[bad[:3]])
+        same, mx = ck.image_diff(rgb, o_rgb)
+        assert mx <= 2 and same >= 0.999, (seed, counters, same, mx)
+        if counters:
+            assert st["rays"] == o_ctr["rays"] and st["tri_tests"] == o_ctr["tri_tests"], (seed, st, o_ctr)
+    ds.set_consistent(True)
+    c_rgb, c_hits, _, _ = ck.oracle_render(hs.desc, cam, consistent=True)
+    rgb, hits, _ = ds.render(cam, want_hits=True)
+    assert len(ck.compare_hits(hits, c_hits, allow_src_unknown=False)) == 0, seed
+    same, mx = ck.image_diff(rgb, c_rgb)
+    assert mx <= 2 and same >= 0.999, (seed, "consistent", same, mx)
+    ds.close(); hs.close()
