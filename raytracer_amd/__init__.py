@@ -174,9 +174,16 @@ class DeviceScene:
         if self._lib.rtx_scene_update_lights(self._h, arr, len(lights)) != 0:
             raise RtxError(self._lib.rtx_last_error().decode())
 
-    def render(self, cam: Camera, want_hits: bool = False):
-        """Whole frame -> (rgb[h][w][3] uint8, hit records or None, stats dict)."""
-        rgb = np.empty((cam.height, cam.width, 3), dtype=np.uint8)
+    def render(self, cam: Camera, want_hits: bool = False, out=None):
+        """Whole frame -> (rgb[h][w][3] uint8, hit records or None, stats dict).
+        ``out``: a C-contiguous uint8 array of h*w*3 bytes to receive the image instead of a new
+        one (reused from frame to frame; page-locked memory makes the download a direct DMA)."""
+        if out is None:
+            rgb = np.empty((cam.height, cam.width, 3), dtype=np.uint8)
+        else:
+            if out.dtype != np.uint8 or not out.flags["C_CONTIGUOUS"] or out.size != cam.height * cam.width * 3:
+                raise RtxError("out must be a C-contiguous uint8 array of height * width * 3 bytes")
+            rgb = out.reshape(cam.height, cam.width, 3)
         hits = np.empty(cam.height * cam.width, dtype=HIT_DTYPE) if want_hits else None
         st = Stats()
         rc = self._lib.rtx_render(self._h, C.byref(cam), cam.width, cam.height, 0, 1,

@@ -725,6 +725,7 @@ int rtx_render(rtx_scene* sc, const rtx_camera* cam, int32_t tw, int32_t th, int
         sc->queue_capacity = (uint32_t)std::min<int64_t>(want, 0x7FFFFFF0);
     }
     uint32_t overflows = 0;
+    std::vector<Counters> per_gen((size_t)G);
     float kernel_ms = 0.f, trace_ms = 0.f;
     uint32_t trace_launches = 0;
     while (true) {
@@ -802,6 +803,13 @@ int rtx_render(rtx_scene* sc, const rtx_camera* cam, int32_t tw, int32_t th, int
         HIP_TRY(hipEventRecord(gev[2 * G], sc->stream));
         HIP_TRY(hipEventRecord(sc->ev1, sc->stream));
         HIP_TRY(hipGetLastError());
+        // The results follow the kernels down the stream before it is known whether a ray queue
+        // overflowed (that is rare, and the frame is then rendered and copied again): one wait
+        // for kernels, control block and results together.
+        if (rgb_is_device) HIP_TRY(hipMemcpyAsync(rgb_out, sc->rgb.p, (size_t)n_local_px * 3, hipMemcpyDeviceToDevice, sc->stream));
+        else HIP_TRY(hipMemcpyAsync(rgb_out, sc->rgb.p, (size_t)n_local_px * 3, hipMemcpyDeviceToHost, sc->stream));
+        if (hit_ids) HIP_TRY(hipMemcpyAsync(hit_ids, sc->aov.p, (size_t)cam->width * cam->height * sizeof(rtx_hit_id), hipMemcpyDeviceToHost, sc->stream));
+        if (sc->counters_on) HIP_TRY(hipMemcpyAsync(per_gen.data(), sc->counters.p, per_gen.size() * sizeof(Counters), hipMemcpyDeviceToHost, sc->stream));
         std::vector<GenCtrl> ctrl((size_t)G + 1);
         HIP_TRY(hipMemcpyAsync(ctrl.data(), sc->ctrl.p, ctrl.size() * sizeof(GenCtrl), hipMemcpyDeviceToHost, sc->stream));
         HIP_TRY(hipStreamSynchronize(sc->stream));
@@ -846,13 +854,7 @@ int rtx_render(rtx_scene* sc, const rtx_camera* cam, int32_t tw, int32_t th, int
         if (overflows > 8) return fail(RTX_ENOMEM, "ray queues kept overflowing");
     }
 
-    if (rgb_is_device) HIP_TRY(hipMemcpyAsync(rgb_out, sc->rgb.p, (size_t)n_local_px * 3, hipMemcpyDeviceToDevice, sc->stream));
-    else HIP_TRY(hipMemcpyAsync(rgb_out, sc->rgb.p, (size_t)n_local_px * 3, hipMemcpyDeviceToHost, sc->stream));
-    if (hit_ids) HIP_TRY(hipMemcpyAsync(hit_ids, sc->aov.p, (size_t)cam->width * cam->height * sizeof(rtx_hit_id), hipMemcpyDeviceToHost, sc->stream));
     Counters ctr{};
-    std::vector<Counters> per_gen((size_t)G);
-    if (sc->counters_on) HIP_TRY(hipMemcpyAsync(per_gen.data(), sc->counters.p, per_gen.size() * sizeof(Counters), hipMemcpyDeviceToHost, sc->stream));
-    HIP_TRY(hipStreamSynchronize(sc->stream));
     if (sc->counters_on) {
         static_assert(sizeof(Counters) % sizeof(unsigned long long) == 0, "Counters is an array of u64");
         for (const Counters& c : per_gen)
