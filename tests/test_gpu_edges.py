@@ -106,3 +106,30 @@ def test_many_tiny_tiles(tmp_path):
         same, mx = ck.image_diff(frame, full)
         assert mx <= 1 and same >= 0.995, (tile, world, same, mx)
     ds.close(); hs.close()
+
+
+def test_queues_regrow_when_a_larger_frame_follows(tmp_path):
+    """The ray queues are sized by the first frame; a much larger one overflows them, the
+    library grows them and renders the frame again -- with the same result as a fresh scene."""
+    path = scenes.scene_tiny(str(tmp_path), res=(16, 12))
+    hs = rt.HostScene(path)
+    ds = rt.DeviceScene(hs.desc, 0)
+    cam, _ = hs.camera(0)
+    ds.render(cam)
+    big = type(cam).from_buffer_copy(cam)
+    big.width, big.height = 400, 300
+    rgb, hits, st = ds.render(big, want_hits=True)
+    assert st["queue_overflows"] >= 1
+    fresh = rt.DeviceScene(hs.desc, 0)
+    rgb2, hits2, st2 = fresh.render(big, want_hits=True)
+    assert st2["queue_overflows"] == 0
+    assert np.array_equal(hits, hits2)
+    same, mx = ck.image_diff(rgb, rgb2)
+    assert mx <= 1 and same >= 0.9999
+    o_rgb, o_hits, _, _ = ck.oracle_render(hs.desc, big)
+    assert len(ck.compare_hits(hits, o_hits, allow_src_unknown=False)) == 0
+    same, mx = ck.image_diff(rgb, o_rgb)
+    assert mx <= 2 and same >= 0.999
+    again, _, st3 = ds.render(big)                       # the grown queues are kept
+    assert st3["queue_overflows"] == 0 and ck.image_diff(again, rgb)[1] <= 1
+    ds.close(); fresh.close(); hs.close()
