@@ -949,14 +949,28 @@ void dump(const rtx_host_scene& s, const std::string& path) {
     fclose(f);
 }
 
-uint32_t crc32_update(uint32_t crc, const unsigned char* p, size_t n) {
-    static uint32_t table[256];
-    static bool init = false;
-    if (!init) {
-        for (uint32_t i = 0; i < 256; i++) { uint32_t c = i; for (int k = 0; k < 8; k++) c = (c & 1) ? 0xEDB88320u ^ (c >> 1) : c >> 1; table[i] = c; }
-        init = true;
+// CRC-32 of PNG chunks, eight bytes per step (slicing tables built on first use).
+struct CrcTables {
+    uint32_t t[8][256];
+    CrcTables() {
+        for (uint32_t i = 0; i < 256; i++) { uint32_t c = i; for (int k = 0; k < 8; k++) c = (c & 1) ? 0xEDB88320u ^ (c >> 1) : c >> 1; t[0][i] = c; }
+        for (uint32_t i = 0; i < 256; i++)
+            for (int k = 1; k < 8; k++) t[k][i] = t[0][t[k - 1][i] & 0xFF] ^ (t[k - 1][i] >> 8);
     }
-    for (size_t i = 0; i < n; i++) crc = table[(crc ^ p[i]) & 0xFF] ^ (crc >> 8);
+};
+
+uint32_t crc32_update(uint32_t crc, const unsigned char* p, size_t n) {
+    static const CrcTables T;
+    const uint32_t (*t)[256] = T.t;
+    while (n >= 8) {
+        uint32_t lo, hi;
+        memcpy(&lo, p, 4); memcpy(&hi, p + 4, 4);         // (little-endian host)
+        lo ^= crc;
+        crc = t[7][lo & 0xFF] ^ t[6][(lo >> 8) & 0xFF] ^ t[5][(lo >> 16) & 0xFF] ^ t[4][lo >> 24] ^
+              t[3][hi & 0xFF] ^ t[2][(hi >> 8) & 0xFF] ^ t[1][(hi >> 16) & 0xFF] ^ t[0][hi >> 24];
+        p += 8; n -= 8;
+    }
+    for (size_t i = 0; i < n; i++) crc = t[0][(crc ^ p[i]) & 0xFF] ^ (crc >> 8);
     return crc;
 }
 
@@ -1141,7 +1155,11 @@ int rtx_host_write_png(const char* path, const uint8_t* rgb, int width, int heig
         z.push_back((unsigned char)(n & 0xFF)); z.push_back((unsigned char)(n >> 8));
         z.push_back((unsigned char)(~n & 0xFF)); z.push_back((unsigned char)((~n >> 8) & 0xFF));
         z.insert(z.end(), raw.begin() + (long)off, raw.begin() + (long)(off + n));
-        for (size_t i = 0; i < n; i++) { a = (a + raw[off + i]) % 65521u; b = (b + a) % 65521u; }
+        for (size_t i = 0; i < n;) {                      // Adler-32, reduced once per 5552 bytes (no overflow before)
+            const size_t end = std::min(n, i + 5552);
+            for (; i < end; i++) { a += raw[off + i]; b += a; }
+            a %= 65521u; b %= 65521u;
+        }
         off += n;
         if (last) break;
     }

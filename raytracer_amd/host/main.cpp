@@ -49,10 +49,11 @@ struct OutputJob {
     bool png = false;
 };
 
-// Writes pictures in the background; at most kDepth of them wait (each is a full frame).
+// Writes pictures in the background, kThreads files at a time (an ASCII P3 file takes longer to
+// format than its frame takes to render); at most kDepth pictures wait (each is a full frame).
 class Writer {
 public:
-    Writer() : worker_([this] { run(); }) {}
+    Writer() { for (int i = 0; i < kThreads; i++) workers_.emplace_back([this] { run(); }); }
     ~Writer() { finish(); }
     void push(OutputJob&& job) {
         std::unique_lock<std::mutex> lk(m_);
@@ -66,13 +67,14 @@ public:
             if (done_) return !failed_;
             done_ = true;
         }
-        work_.notify_one();
-        worker_.join();
+        work_.notify_all();
+        for (std::thread& t : workers_) t.join();
         return !failed_;
     }
 
 private:
-    static constexpr size_t kDepth = 3;
+    static constexpr size_t kDepth = 8;
+    static constexpr int kThreads = 4;
     void run() {
         while (true) {
             OutputJob job;
@@ -103,7 +105,7 @@ private:
     std::deque<OutputJob> queue_;
     bool done_ = false;
     std::atomic<bool> failed_{false};
-    std::thread worker_;
+    std::vector<std::thread> workers_;
 };
 
 }  // namespace
