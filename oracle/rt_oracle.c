@@ -57,7 +57,8 @@ typedef struct { v3 o, d; int depth; } ray_t;
  *    space (bound / |M^-1 d| as the reference normalises it), and a hit whose world distance
  *    is not below the bound leaves bound and record untouched;
  *  - a shadow ray starts with the light's distance as its bound and is occluded iff any hit
- *    is accepted (any_hit: a transformed mesh accepts on the object-space test alone).
+ *    is accepted (any_hit: a transformed mesh accepts on the object-space test alone); the hit
+ *    flag of a record means exactly that.
  * With both flags 0 every function below is the reference's. */
 typedef struct {
     const rtx_scene_desc* s;
@@ -466,6 +467,10 @@ static isect_t intersect_within(const ctx_t* cx, const ray_t* ray, double t_min)
         }
     }
 
+    /* consistent mode: the flag of the returned record means "a hit was accepted" (in the
+     * reference a transformed free triangle that is found but then rejected leaves the flag set,
+     * utils.cpp:692-729, which its callers read) */
+    if (cx->consistent) is.hit = hit;
     if (!hit) return is;
 
     const double u = is.beta, v = is.gamma, w = 1.0 - u - v;          /* utils.cpp:807-853 */

@@ -1,6 +1,8 @@
 """Seeded random scenes (scenes.scene_random): the CPU restatement against the compiled
 reference, where that is present.  Image bytes and primary-hit records must be equal, with and
 without back-face culling."""
+import os
+
 import numpy as np
 import pytest
 
@@ -8,7 +10,7 @@ import _checkers as ck
 import raytracer_amd as rt
 from raytracer_amd import scenes
 
-SEEDS = list(range(32))
+SEEDS = list(range(int(os.environ.get("RTX_FUZZ_SEEDS", "32"))))      # RTX_FUZZ_SEEDS=N widens the sweep
 
 
 @pytest.mark.skipif(not ck.have_reference(), reason="compiled reference (oracle/_ref) not present")
