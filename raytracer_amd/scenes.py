@@ -527,14 +527,15 @@ UNIT_SCENES = {
 }
 
 
-def scene_random(out_dir, seed, res=(56, 40)):
+def scene_random(out_dir, seed, res=(56, 40), detail=1):
     """Seeded random scene for fuzzing the hot path against its checkers: a ground quad, 1-4
     small bumpy meshes (flat or smooth, some with transforms of their own), 0-30 instances
     (of meshes and of other instances, with and without ``_resetTransform``, scales below and
     above one, mirrored ones), up to two spheres, sometimes a plane and a free triangle, 1-3
-    lights, every material type, recursion depth 0-4."""
+    lights, every material type, recursion depth 0-4.  ``detail`` multiplies the meshes' resolution
+    in both directions (deep trees, long traversals)."""
     rng = np.random.default_rng(10_000 + seed)
-    name = f"random_{seed:03d}"
+    name = f"random_{seed:03d}" + (f"_x{detail}" if detail != 1 else "")
     verts = [(-25.0, 0.0, 25.0), (25.0, 0.0, 25.0), (25.0, 0.0, -25.0), (-25.0, 0.0, -25.0)]
     mats = [_mat(1, (1, 1, 1), (0.55, 0.5, 0.45), (0.3, 0.3, 0.3), phong=12),
             _mat(2, (0.2, 0.2, 0.2), (0.1, 0.1, 0.1), (0.5, 0.5, 0.5), phong=80, mirror=(0.8, 0.8, 0.8), mtype="mirror"),
@@ -568,7 +569,7 @@ def scene_random(out_dir, seed, res=(56, 40)):
     next_id = 2
     n_base = int(rng.integers(1, 5))
     for b in range(n_base):
-        v, f = bumpy_sphere(int(rng.integers(6, 14)), int(rng.integers(4, 9)), radius=float(rng.uniform(0.5, 1.3)),
+        v, f = bumpy_sphere(detail * int(rng.integers(6, 14)), detail * int(rng.integers(4, 9)), radius=float(rng.uniform(0.5, 1.3)),
                             bump=0.25, seed=int(rng.integers(1 << 30)),
                             center=(float(rng.uniform(-4, 4)), float(rng.uniform(0.6, 1.6)), float(rng.uniform(-4, 3))))
         base = len(verts)

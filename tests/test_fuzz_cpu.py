@@ -32,3 +32,18 @@ def test_random_scenes_are_deterministic(tmp_path):
     a = open(scenes.scene_random(str(tmp_path / "a"), 5)).read()
     b = open(scenes.scene_random(str(tmp_path / "b"), 5)).read()
     assert a == b and a != open(scenes.scene_random(str(tmp_path / "c"), 6)).read()
+
+
+@pytest.mark.skipif(not ck.have_reference(), reason="compiled reference (oracle/_ref) not present")
+@pytest.mark.parametrize("seed", [1, 2, 9])
+def test_oracle_equals_reference_on_detailed_random_scene(tmp_path, seed):
+    """Meshes of 10-40 thousand faces (deep trees) instead of a few hundred."""
+    path = scenes.scene_random(str(tmp_path), seed, res=(120, 88), detail=12)
+    prefix = str(tmp_path / "ref")
+    ck.reference_dump(path, prefix)
+    hs = rt.HostScene(path)
+    cam, _ = hs.camera(0)
+    rgb, hits, _, _ = ck.oracle_render(hs.desc, cam)
+    assert np.array_equal(rgb, ck.read_rgb(prefix + ".cam0.rgb", cam.width, cam.height))
+    assert len(ck.compare_hits(hits, ck.read_hits(prefix + ".cam0.hits"))) == 0
+    hs.close()

@@ -40,3 +40,21 @@ def test_random_scene_matches_oracle(tmp_path, seed):
     same, mx = ck.image_diff(rgb, c_rgb)
     assert mx <= 2 and same >= 0.999, (seed, "consistent", same, mx)
     ds.close(); hs.close()
+
+
+@pytest.mark.parametrize("seed", [1, 2, 6, 9, 13, 21, 34, 55])
+def test_detailed_random_scene_matches_oracle(tmp_path, seed):
+    """The same with meshes of 10-40 thousand faces at 288x208: traversals long enough for the
+    wave-wide finishing of drained waves and for the tiny-generation kernel."""
+    path = scenes.scene_random(str(tmp_path), seed, res=(288, 208), detail=12)
+    hs = rt.HostScene(path, True, bool(seed & 1))
+    ds = rt.DeviceScene(hs.desc, 0)
+    cam, _ = hs.camera(0)
+    for consistent in (False, True):
+        ds.set_consistent(consistent)
+        o_rgb, o_hits, _, _ = ck.oracle_render(hs.desc, cam, consistent=consistent)
+        rgb, hits, _ = ds.render(cam, want_hits=True)
+        assert len(ck.compare_hits(hits, o_hits, allow_src_unknown=False)) == 0, (seed, consistent)
+        same, mx = ck.image_diff(rgb, o_rgb)
+        assert mx <= 2 and same >= 0.999, (seed, consistent, same, mx)
+    ds.close(); hs.close()
