@@ -443,6 +443,9 @@ enum { LS_EMPTY = 0, LS_NEED_JOB = 1, LS_JOB_DONE = 2, LS_IN_JOB = 3 };
 #ifndef RTX_SCATTER_SHIFT_THIN
 #define RTX_SCATTER_SHIFT_THIN 0           // log2 of their group size
 #endif
+#ifndef RTX_REPLAY_CAP
+#define RTX_REPLAY_CAP 3             // instance candidates a lane may turn down per service visit before it yields (instance-heavy scenes)
+#endif
 #ifndef RTX_LDS_OBJS
 #define RTX_LDS_OBJS 12              // object records (512 B each) kept in LDS per block: the first so many of the scene
 #endif
@@ -546,14 +549,21 @@ RTX_DEV void ray_begin(const Scene& S, Lane& L, const RecOut& out, const double 
     L.state = LS_NEED_JOB;
 }
 
-// Advance the lane's object iterator until an object needs traversal (returns true, job set
-// up: rayHitsMesh's prologue, utils.cpp:418-494 + the root test of bvh.cpp:132) or the
-// object sequence is exhausted (returns false).
-template <bool COUNT, bool FAST>
-RTX_DEV bool job_next(const Scene& S, const ObjCache& oc, Lane& L, const RecOut& out, unsigned* inst_bits, const double light_dist, Tally& tl) {
+// Advance the lane's object iterator until an object needs traversal (returns 1, job set
+// up: rayHitsMesh's prologue, utils.cpp:418-494 + the root test of bvh.cpp:132), the object
+// sequence is exhausted (returns 0), or the lane has turned down CAP instance candidates in
+// this call (returns 2: call again in the next service pass).
+template <bool COUNT, bool FAST, int CAP>
+RTX_DEV int job_next(const Scene& S, const ObjCache& oc, Lane& L, const RecOut& out, unsigned* inst_bits, const double light_dist, Tally& tl) {
     const unsigned n_summary = rtx_summary_words(S.n_insts);
     const Slab ws = make_slab(L.o, L.d);         // world-space slab constants, once per call
+    int turned_down = 0;
     while (true) {
+        // A service pass lasts as long as its slowest lane.  A lane that keeps turning instance
+        // candidates down (each a chain of dependent loads) yields after CAP of them and goes on in
+        // the next pass, instead of holding up the lanes that already have their jobs (CAP = 0: no
+        // limit; the variant for scenes with few instances has none).
+        if (CAP > 0 && L.it > S.n_meshes && turned_down++ >= CAP) return 2;
         int oi;
         if (L.it < S.n_meshes) {                                     // utils.cpp:736-739
             oi = L.it; L.it++;
@@ -597,13 +607,13 @@ RTX_DEV bool job_next(const Scene& S, const ObjCache& oc, Lane& L, const RecOut&
                         L.orig_t_min = L.t_min;
                         L.ro = L.o; L.rd = L.d; L.ix = ws.ix; L.iy = ws.iy; L.iz = ws.iz; L.par = ws.par;
                         L.cur_ref = S.tl_key; L.cur_cnt = 0; L.sp = 0; L.btri = -1;
-                        return true;
+                        return 1;
                     }
                 }
             }
             while (L.bits == 0u) {
                 while (L.sbits == 0u) {
-                    if (L.sword >= L.whi) return false;
+                    if (L.sword >= L.whi) return 0;
                     L.sword++;
                     L.sbits = atomicExch(inst_bits + L.sword, 0u);           // summary words come first in the lane's area
                 }
@@ -679,7 +689,7 @@ RTX_DEV bool job_next(const Scene& S, const ObjCache& oc, Lane& L, const RecOut&
         }
         L.ro = ro; L.rd = rd; L.ix = sl.ix; L.iy = sl.iy; L.iz = sl.iz; L.par = sl.par;
         L.cur_ref = root_ref; L.cur_cnt = root_count; L.sp = 0; L.btri = -1;
-        return true;
+        return 1;
     }
 }
 
@@ -931,7 +941,7 @@ RTX_DEV V3 primary_direction(const Frame& F, int px, int py) {
 
 // Divergent per-lane part of a service pass.  `fresh`: the lane has just been handed a new ray
 // (L.slot / L.o / L.d / L.is_shadow set).
-template <bool COUNT, bool FAST>
+template <bool COUNT, bool FAST, int CAP>
 RTX_DEV void service_lane(const Launch* __restrict__ Lp, const ObjCache& oc, const int gen, double* __restrict__ accum,
                           rtx_hit_id* __restrict__ aov, Lane& L, unsigned* inst_bits, const bool fresh, Tally& tl) {
     const Scene& S = Lp->S;
@@ -989,9 +999,10 @@ RTX_DEV void service_lane(const Launch* __restrict__ Lp, const ObjCache& oc, con
         }
         L.bits = 0u; L.sbits = 0u; L.sword = L.whi;
     }
-    const bool more = !decided && job_next<COUNT, FAST>(S, oc, L, out, inst_bits, light_dist, tl);
+    const int more = decided ? 0 : job_next<COUNT, FAST, CAP>(S, oc, L, out, inst_bits, light_dist, tl);
     if (COUNT) { const long long c = clock64(); tl.sec[2] += (unsigned long long)(c - c0); tl.sec[6]++; c0 = c; }
-    if (more) { L.state = LS_IN_JOB; return; }
+    if (more == 1) { L.state = LS_IN_JOB; return; }
+    if (more == 2) { L.state = LS_NEED_JOB; return; }          // yielded: more candidates next time
     // ---- ray complete ------------------------------------------------------------------------
     const bool hit = L.hit != 0;
     if (L.is_shadow) {                                            // utils.cpp:1083
@@ -1632,7 +1643,7 @@ k_trace(const Launch* __restrict__ Lp, GenCtrl* ctrl, const int gen, double* __r
                     }
                 }
                 if (fresh || L.state == LS_JOB_DONE || L.state == LS_NEED_JOB)
-                    service_lane<COUNT, FAST>(Lp, oc, gen, accum, aov, L, inst_bits, fresh, tl);
+                    service_lane<COUNT, FAST, (WIDE == 0 && !COUNT) ? RTX_REPLAY_CAP : 0>(Lp, oc, gen, accum, aov, L, inst_bits, fresh, tl);
                 if (drained || __ballot(L.state == LS_EMPTY) == 0ull) break;
             }
             if (COUNT) { tl.clk_serv += (unsigned long long)(clock64() - c0); tl.passes++; }
