@@ -453,7 +453,7 @@ enum { LS_EMPTY = 0, LS_NEED_JOB = 1, LS_JOB_DONE = 2, LS_IN_JOB = 3 };
 #define RTX_SCATTER0_SHIFT 6         // generation 0: whole 8x8 pixel blocks (64 items) are scattered
 #endif
 #ifndef RTX_SCATTER_SHIFT
-#define RTX_SCATTER_SHIFT 4          // rays of later generations are handed out in scattered groups of 16
+#define RTX_SCATTER_SHIFT 12         // rays of later generations are handed out in scattered groups of 4096 (finer costs locality)
 #endif
 #ifndef RTX_CHUNK
 #define RTX_CHUNK 64                 // rays a wave claims per atomic, at most ...
