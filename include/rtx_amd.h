@@ -42,7 +42,9 @@ enum {
     RTX_ENODEVICE = -2,  /* no HIP device, or device index out of range */
     RTX_EHIP = -3,       /* a HIP runtime call failed                   */
     RTX_ENOMEM = -4,     /* ray queues would exceed the configured cap  */
-    RTX_ELIMIT = -5      /* a structural limit was exceeded (BVH depth) */
+    RTX_ELIMIT = -5      /* a structural limit was exceeded: BVH or instance hierarchy deeper than the
+                            traversal stack (at creation, or detected on the device while rendering --
+                            no picture is returned then), frame too large for one call */
 };
 
 /* Intersection::Kind, in the reference's enum order (scene.h:256). */
@@ -171,13 +173,16 @@ int rtx_scene_update_lights(rtx_scene* scene, const rtx_light* lights, int32_t n
 /* Render one camera: the replacement for multiThreadedRayTracing (raytracer.cpp:93-141).
  *  tile_w/tile_h/tile_first/tile_stride select an interleaved subset of tile_w x tile_h
  *  pixel tiles (row-major tile numbering): tiles tile_first, tile_first+tile_stride, ...
- *  Pass tile_stride = 1, tile_first = 0 (any tile size) for the whole frame.
- *  rgb_out receives the selected tiles' pixels: for the whole frame this is the reference's
- *  image layout (row-major, RGB interleaved, row 0 on top, raytracer.cpp:78-80); for a tile
- *  subset the tiles are packed one after another, each tile_h rows of tile_w pixels
- *  (edge tiles are clipped but still occupy a full tile_w*tile_h*3 slot).
+ *  The whole frame in the reference's image layout (row-major, RGB interleaved, row 0 on top,
+ *  raytracer.cpp:78-80; width*height*3 bytes) is ONE tile: tile_w = width, tile_h = height,
+ *  tile_first = 0, tile_stride = 1.
+ *  Any other tiling -- also tile_first = 0, tile_stride = 1 with smaller tiles, which selects
+ *  every tile -- writes the selected tiles PACKED one after another, each tile_h rows of
+ *  tile_w pixels; a tile clipped by the image edge still occupies a full tile_w*tile_h*3
+ *  slot, so the buffer can be larger than width*height*3: size it with
+ *  rtx_render_output_bytes and bring it into image order with rtx_unpack_tiles.
  *  rgb_is_device != 0: rgb_out is a device pointer on the scene's device.
- *  hit_ids (host pointer or NULL): w*h records, whole-frame renders only.
+ *  hit_ids (host pointer or NULL): w*h records, one-tile (whole-frame) renders only.
  *  stats may be NULL.  Blocking. */
 int rtx_render(rtx_scene* scene, const rtx_camera* camera,
                int32_t tile_w, int32_t tile_h, int32_t tile_first, int32_t tile_stride,

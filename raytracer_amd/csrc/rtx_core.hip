@@ -63,9 +63,15 @@ struct HBox {
 
 struct rtx_scene {
     int device = 0;
+    int cus = 256;                  // compute units of the device (hipDeviceProp_t::multiProcessorCount)
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::vector<hipEvent_t> gen_events;   // 2 per generation + 1: brackets of the trace launches
+    // page-locked staging, sized at creation: the frame's Launch block on its way to the device,
+    // the control blocks and counters on their way back (no pageable copies, nothing allocated per frame)
+    Launch* h_launch = nullptr;
+    GenCtrl* h_ctrl = nullptr;
+    Counters* h_counters = nullptr;
     Scene dev{};                    // kernel argument (device pointers inside)
     int n_meshes = 0;
     bool counters_on = false;
@@ -81,6 +87,9 @@ struct rtx_scene {
         if (ev0) (void)hipEventDestroy(ev0);
         if (ev1) (void)hipEventDestroy(ev1);
         if (stream) (void)hipStreamDestroy(stream);
+        if (h_launch) (void)hipHostFree(h_launch);
+        if (h_ctrl) (void)hipHostFree(h_ctrl);
+        if (h_counters) (void)hipHostFree(h_counters);
     }
 };
 
@@ -178,8 +187,10 @@ int flatten_mesh(const rtx_scene_desc& d, const rtx_mesh& m, Flat& F) {
             max_depth = std::max(max_depth, dep);
             if (m.nodes[i].left != -1) { st.emplace_back(m.nodes[i].left, dep + 1); st.emplace_back(m.nodes[i].right, dep + 1); }
         }
-        if (3 * ((max_depth + 1) / 2) > RTX_STACK - 2) return fail(RTX_ELIMIT, "BVH deeper than the traversal stack");
-        F.record_levels = std::max(F.record_levels, (max_depth + 1) / 2 + 1);
+        // (max_depth counts the nodes on the longest root-to-leaf path; a record stands for an inner
+        // node at an even level, so a path crosses max_depth / 2 records)
+        if (3 * (max_depth / 2) > RTX_STACK) return fail(RTX_ELIMIT, "BVH deeper than the traversal stack");
+        F.record_levels = std::max(F.record_levels, max_depth / 2 + 1);
     }
     // collapse two binary levels per record, records in DFS pre-order
     struct Collapse {
@@ -446,6 +457,8 @@ int build_scene(rtx_scene& sc, const rtx_scene_desc& d) {
         const HBox all = tb.range_box(0, (int)items.size());
         memcpy(S.tl_min, all.mn, 24); memcpy(S.tl_max, all.mx, 24);
         tlas_root = tb.make(0, (int)items.size());
+        // the walk pushes up to three entries per record level, like a BLAS traversal
+        if (3 * (tb.max_level + 1) > RTX_STACK) return fail(RTX_ELIMIT, "instance hierarchy deeper than the traversal stack");
         F.record_levels = std::max(F.record_levels, tb.max_level + 1);
         S.n_insts = d.n_instances;
     }
@@ -567,9 +580,22 @@ int rtx_scene_create(const rtx_scene_desc* desc, int device, rtx_scene** out) {
     sc->device = device;
     int rc = build_scene(*sc, *desc);
     if (rc == RTX_OK) {
+        // everything a frame needs besides device memory is created here, once
+        const size_t G = (size_t)sc->dev.max_depth + 2;
         hipError_t e = hipStreamCreateWithFlags(&sc->stream, hipStreamNonBlocking);
         if (e == hipSuccess) e = hipEventCreate(&sc->ev0);
         if (e == hipSuccess) e = hipEventCreate(&sc->ev1);
+        for (size_t k = 0; k < 2 * G + 1 && e == hipSuccess; k++) {
+            hipEvent_t ev;
+            e = hipEventCreate(&ev);
+            if (e == hipSuccess) sc->gen_events.push_back(ev);
+        }
+        if (e == hipSuccess) e = hipHostMalloc((void**)&sc->h_launch, sizeof(Launch), hipHostMallocDefault);
+        if (e == hipSuccess) e = hipHostMalloc((void**)&sc->h_ctrl, (G + 1) * sizeof(GenCtrl), hipHostMallocDefault);
+        if (e == hipSuccess) e = hipHostMalloc((void**)&sc->h_counters, G * sizeof(Counters), hipHostMallocDefault);
+        hipDeviceProp_t prop;
+        if (e == hipSuccess && hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
+            sc->cus = prop.multiProcessorCount;
         if (e != hipSuccess) rc = fail(RTX_EHIP, hipGetErrorString(e));
     }
     if (rc != RTX_OK) { delete sc; return rc; }
@@ -640,8 +666,28 @@ int rtx_unpack_tiles(const uint8_t* packed, int32_t width, int32_t height, int32
     return RTX_OK;
 }
 
-int rtx_render(rtx_scene* sc, const rtx_camera* cam, int32_t tw, int32_t th, int32_t first, int32_t stride,
-               uint8_t* rgb_out, int32_t rgb_is_device, rtx_hit_id* hit_ids, rtx_stats* stats) {
+}  // extern "C"
+
+namespace {
+
+// Device memory one frame works in.
+struct FrameMem {
+    void *accum = nullptr, *rgb = nullptr, *ctrl = nullptr, *counters = nullptr, *aov = nullptr, *stacks = nullptr;
+    void *launch = nullptr, *hitbuf = nullptr, *queue[2] = {nullptr, nullptr};
+    unsigned* inst_bits = nullptr;
+    uint32_t queue_capacity = 0;      // rays per queue
+    size_t hit_capacity = 0;
+};
+
+// Synchronise the stream when a render call leaves early: copies into the caller's buffers and
+// into the scene's staging memory may still be in flight.
+struct StreamGuard {
+    hipStream_t s; bool armed = true;
+    ~StreamGuard() { if (armed) (void)hipStreamSynchronize(s); }
+};
+
+int render_frame(rtx_scene* sc, const rtx_camera* cam, int32_t tw, int32_t th, int32_t first, int32_t stride,
+                 uint8_t* rgb_out, int32_t rgb_is_device, rtx_hit_id* hit_ids, rtx_stats* stats) {
     if (!sc || !cam || !rgb_out) return fail(RTX_EINVAL, "null argument");
     TileGeom g;
     int rc = tile_geometry(cam, tw, th, first, stride, g);
@@ -694,40 +740,38 @@ int rtx_render(rtx_scene* sc, const rtx_camera* cam, int32_t tw, int32_t th, int
     }
 
     const int G = sc->dev.max_depth + 2;
-    HIP_TRY(sc->accum.ensure((size_t)n_local_px * 3 * sizeof(double)));
-    HIP_TRY(sc->rgb.ensure((size_t)n_local_px * 3));
-    HIP_TRY(sc->ctrl.ensure((size_t)(G + 1) * sizeof(GenCtrl)));
-    HIP_TRY(sc->counters.ensure((size_t)G * sizeof(Counters)));      // one block per generation
-    if (hit_ids) HIP_TRY(sc->aov.ensure((size_t)cam->width * cam->height * sizeof(rtx_hit_id)));
-
-    int dev_cus = 256;
-    {
-        hipDeviceProp_t prop;
-        if (hipGetDeviceProperties(&prop, sc->device) == hipSuccess && prop.multiProcessorCount > 0) dev_cus = prop.multiProcessorCount;
-    }
     // One grid of resident blocks: RTX_TRACE_WAVES waves per SIMD = that many 256-thread blocks per CU.
-    const unsigned persistent_blocks = (unsigned)dev_cus * (unsigned)RTX_TRACE_WAVES;
-    HIP_TRY(sc->stacks.ensure((size_t)persistent_blocks * 256u * RTX_STACK * 16u));
-    // one bit per instance per lane; every ray leaves its lane's bitmap clear, so it is zeroed once
+    const unsigned persistent_blocks = (unsigned)sc->cus * (unsigned)RTX_TRACE_WAVES;
+    // one bit per instance per lane; every ray leaves its lane's bitmap clear
     const uint32_t inst_words = rtx_bitmap_words(sc->dev.n_insts) + rtx_summary_words(sc->dev.n_insts);
-    {
-        const size_t bytes = (size_t)persistent_blocks * 256u * inst_words * sizeof(uint32_t);
-        if (bytes > ((size_t)8 << 30)) return fail(RTX_ELIMIT, "too many instances for the per-lane instance bitmaps");
-        if (bytes > sc->inst_bits.bytes || sc->inst_bits_cleared < bytes) {
-            HIP_TRY(sc->inst_bits.ensure(bytes));
-            HIP_TRY(hipMemsetAsync(sc->inst_bits.p, 0, sc->inst_bits.bytes, sc->stream));
-            sc->inst_bits_cleared = sc->inst_bits.bytes;
-        }
-    }
+    const size_t accum_bytes = (size_t)n_local_px * 3 * sizeof(double);
+    const size_t ctrl_bytes = (size_t)(G + 1) * sizeof(GenCtrl);
+    const size_t stack_bytes = (size_t)persistent_blocks * 256u * RTX_STACK * 16u;
+    const size_t bits_bytes = (size_t)persistent_blocks * 256u * inst_words * sizeof(uint32_t);
+    const int64_t queue_want = std::max<int64_t>(n_local_px * (int64_t)(sc->dev.n_lights + 2), 1 << 12);
 
-    if (sc->queue_capacity == 0) {
-        int64_t want = std::max<int64_t>(n_local_px * (int64_t)(sc->dev.n_lights + 2), 1 << 16);
-        sc->queue_capacity = (uint32_t)std::min<int64_t>(want, 0x7FFFFFF0);
+    FrameMem M;
+    HIP_TRY(sc->accum.ensure(accum_bytes));                     M.accum = sc->accum.p;
+    HIP_TRY(sc->rgb.ensure((size_t)n_local_px * 3));            M.rgb = sc->rgb.p;
+    HIP_TRY(sc->ctrl.ensure(ctrl_bytes));                       M.ctrl = sc->ctrl.p;
+    HIP_TRY(sc->counters.ensure((size_t)G * sizeof(Counters))); M.counters = sc->counters.p;   // one block per generation
+    if (hit_ids) { HIP_TRY(sc->aov.ensure((size_t)cam->width * cam->height * sizeof(rtx_hit_id))); M.aov = sc->aov.p; }
+    HIP_TRY(sc->stacks.ensure(stack_bytes));                    M.stacks = sc->stacks.p;
+    HIP_TRY(sc->launch.ensure(sizeof(Launch)));                 M.launch = sc->launch.p;
+    if (bits_bytes > ((size_t)8 << 30)) return fail(RTX_ELIMIT, "too many instances for the per-lane instance bitmaps");
+    if (bits_bytes > sc->inst_bits.bytes || sc->inst_bits_cleared < bits_bytes) {
+        HIP_TRY(sc->inst_bits.ensure(bits_bytes));
+        HIP_TRY(hipMemsetAsync(sc->inst_bits.p, 0, sc->inst_bits.bytes, sc->stream));    // zeroed once
+        sc->inst_bits_cleared = sc->inst_bits.bytes;
     }
+    M.inst_bits = (unsigned*)sc->inst_bits.p;
+    if (sc->queue_capacity == 0) sc->queue_capacity = (uint32_t)std::min<int64_t>(std::max<int64_t>(queue_want, 1 << 16), 0x7FFFFFF0);
+
+    StreamGuard guard{sc->stream};
     uint32_t overflows = 0;
-    std::vector<Counters> per_gen((size_t)G);
     float kernel_ms = 0.f, trace_ms = 0.f;
     uint32_t trace_launches = 0;
+    const bool poison = getenv("RTX_AMD_POISON_QUEUES") != nullptr;   // test aid: queues and hit records start as 0xFF
     while (true) {
         if ((int64_t)sc->queue_capacity * (int64_t)kRayBytes * 2 > sc->queue_limit) {
             uint32_t cap = (uint32_t)(sc->queue_limit / (2 * (int64_t)kRayBytes));
@@ -737,15 +781,25 @@ int rtx_render(rtx_scene* sc, const rtx_camera* cam, int32_t tw, int32_t th, int
         }
         HIP_TRY(sc->queue[0].ensure((size_t)sc->queue_capacity * kRayBytes));
         HIP_TRY(sc->queue[1].ensure((size_t)sc->queue_capacity * kRayBytes));
-        const size_t hit_cap = std::max<size_t>(sc->queue_capacity, (size_t)n_items0);
-        HIP_TRY(sc->hitbuf.ensure(hit_cap * kHitBytes));
-        Launch launch;
+        M.hit_capacity = std::max<size_t>(sc->queue_capacity, (size_t)n_items0);
+        HIP_TRY(sc->hitbuf.ensure(M.hit_capacity * kHitBytes));
+        M.queue[0] = sc->queue[0].p; M.queue[1] = sc->queue[1].p; M.hitbuf = sc->hitbuf.p;
+        M.queue_capacity = sc->queue_capacity;
+        if (poison) {
+            HIP_TRY(hipMemsetAsync(M.queue[0], 0xFF, (size_t)M.queue_capacity * kRayBytes, sc->stream));
+            HIP_TRY(hipMemsetAsync(M.queue[1], 0xFF, (size_t)M.queue_capacity * kRayBytes, sc->stream));
+            HIP_TRY(hipMemsetAsync(M.hitbuf, 0xFF, M.hit_capacity * kHitBytes, sc->stream));
+        }
+        // page-locked, so the copy below is a plain DMA; the previous frame's (or attempt's) copy of the
+        // block finished before that frame's final wait returned
+        Launch& launch = *sc->h_launch;
         launch.S = sc->dev; launch.F = F;
-        launch.q[0] = make_queue(sc->queue[0].p, sc->queue_capacity);
-        launch.q[1] = make_queue(sc->queue[1].p, sc->queue_capacity);
-        launch.hb = make_hitbuf(sc->hitbuf.p, hit_cap);
-        launch.stacks = sc->stacks.p;
-        launch.inst_bits = (unsigned*)sc->inst_bits.p; launch.inst_words = inst_words;
+        launch.S.limit_flag = &((GenCtrl*)M.ctrl)->limit;
+        launch.q[0] = make_queue(M.queue[0], M.queue_capacity);
+        launch.q[1] = make_queue(M.queue[1], M.queue_capacity);
+        launch.hb = make_hitbuf(M.hitbuf, M.hit_capacity);
+        launch.stacks = M.stacks;
+        launch.inst_bits = M.inst_bits; launch.inst_words = inst_words;
         // A service pass lasts as long as its slowest lane.  Replaying instance candidates makes
         // that long (a chain of dependent loads per candidate), so scenes with many instances
         // gather more lanes per pass.
@@ -756,22 +810,17 @@ int rtx_render(rtx_scene* sc, const rtx_camera* cam, int32_t tw, int32_t th, int
         // every generation's drained waves (a kernel variant of its own; see k_trace)
         launch.chunk_max = sc->dev.n_insts >= 256 ? RTX_CHUNK_INSTANCED : RTX_CHUNK; launch.pad_launch = 0;
         launch.wide_old = (launch.wide_ok && sc->dev.n_insts < 256 && !getenv("RTX_AMD_NO_WIDE_OLD")) ? 1u : 0u;
-        HIP_TRY(sc->launch.ensure(sizeof(Launch)));
-        // pageable source: the copy is staged before the call returns, so `launch` may go out of scope
-        HIP_TRY(hipMemcpyAsync(sc->launch.p, &launch, sizeof launch, hipMemcpyHostToDevice, sc->stream));
-        const Launch* lp = (const Launch*)sc->launch.p;
+        HIP_TRY(hipMemcpyAsync(M.launch, &launch, sizeof launch, hipMemcpyHostToDevice, sc->stream));
+        const Launch* lp = (const Launch*)M.launch;
 
-        HIP_TRY(hipMemsetAsync(sc->ctrl.p, 0, (size_t)(G + 1) * sizeof(GenCtrl), sc->stream));
-        HIP_TRY(hipMemsetAsync(sc->accum.p, 0, (size_t)n_local_px * 3 * sizeof(double), sc->stream));
-        if (sc->counters_on) HIP_TRY(hipMemsetAsync(sc->counters.p, 0, (size_t)G * sizeof(Counters), sc->stream));
+        HIP_TRY(hipMemsetAsync(M.ctrl, 0, ctrl_bytes, sc->stream));
+        HIP_TRY(hipMemsetAsync(M.accum, 0, accum_bytes, sc->stream));
+        if (sc->counters_on) HIP_TRY(hipMemsetAsync(M.counters, 0, (size_t)G * sizeof(Counters), sc->stream));
         // RTX_AMD_GEN_TIMING=1 (development aid): per-generation kernel times on stderr
         static const bool gen_timing = getenv("RTX_AMD_GEN_TIMING") != nullptr;
-        // every trace launch is bracketed by events: rtx_stats.trace_ms is the sum of their durations
-        while (sc->gen_events.size() < (size_t)2 * G + 1) {
-            hipEvent_t e;
-            HIP_TRY(hipEventCreate(&e));
-            sc->gen_events.push_back(e);
-        }
+        // every generation's trace launches (main variant and the one for tiny generations) are
+        // bracketed by events: rtx_stats.trace_ms is the sum of their durations
+        if (sc->gen_events.size() < (size_t)2 * G + 1) return fail(RTX_EHIP, "event pool smaller than the generation count");
         std::vector<hipEvent_t>& gev = sc->gen_events;
         using TraceKernel = void (*)(const Launch*, GenCtrl*, int, double*, rtx_hit_id*, Counters*);
         const TraceKernel trace_main =
@@ -779,40 +828,41 @@ int rtx_render(rtx_scene* sc, const rtx_camera* cam, int32_t tw, int32_t th, int
             : sc->consistent ? (launch.wide_old ? k_trace<false, 1, true> : k_trace<false, 0, true>)
                              : (launch.wide_old ? k_trace<false, 1, false> : k_trace<false, 0, false>);
         const TraceKernel trace_tiny = sc->consistent ? k_trace<false, 2, true> : k_trace<false, 2, false>;
+        const bool two_variants = !sc->counters_on && launch.wide_ok;
         HIP_TRY(hipEventRecord(sc->ev0, sc->stream));
         for (int gen = 0; gen < G; gen++) {
             HIP_TRY(hipEventRecord(gev[2 * gen], sc->stream));
             unsigned blocks = persistent_blocks;
             if (gen == 0) blocks = (unsigned)std::min<int64_t>(persistent_blocks, (n_items0 + 255) / 256);
-            rtx_hit_id* aov = (gen == 0 && hit_ids) ? (rtx_hit_id*)sc->aov.p : nullptr;
-            hipLaunchKernelGGL(trace_main, dim3(blocks), dim3(256), 0, sc->stream, lp, (GenCtrl*)sc->ctrl.p, gen,
-                               (double*)sc->accum.p, aov, sc->counters_on ? (Counters*)sc->counters.p + gen : (Counters*)nullptr);
-            HIP_TRY(hipEventRecord(gev[2 * gen + 1], sc->stream));
+            rtx_hit_id* aov = (gen == 0 && hit_ids) ? (rtx_hit_id*)M.aov : nullptr;
+            hipLaunchKernelGGL(trace_main, dim3(blocks), dim3(256), 0, sc->stream, lp, (GenCtrl*)M.ctrl, gen,
+                               (double*)M.accum, aov, sc->counters_on ? (Counters*)M.counters + gen : (Counters*)nullptr);
             // the variant for tiny generations (one of the two returns at once; see k_trace)
-            if (!sc->counters_on && launch.wide_ok)
-                hipLaunchKernelGGL(trace_tiny, dim3(blocks), dim3(256), 0, sc->stream, lp, (GenCtrl*)sc->ctrl.p, gen,
-                                   (double*)sc->accum.p, aov, (Counters*)nullptr);
+            if (two_variants)
+                hipLaunchKernelGGL(trace_tiny, dim3(blocks), dim3(256), 0, sc->stream, lp, (GenCtrl*)M.ctrl, gen,
+                                   (double*)M.accum, aov, (Counters*)nullptr);
+            HIP_TRY(hipEventRecord(gev[2 * gen + 1], sc->stream));
             // the last generation holds shadow rays only: nothing left to shade
             if (gen + 1 < G)
-                hipLaunchKernelGGL(k_shade, dim3(blocks), dim3(256), 0, sc->stream, lp, (GenCtrl*)sc->ctrl.p, gen,
-                                   (double*)sc->accum.p);
+                hipLaunchKernelGGL(k_shade, dim3(blocks), dim3(256), 0, sc->stream, lp, (GenCtrl*)M.ctrl, gen,
+                                   (double*)M.accum);
         }
         const unsigned n_values = (unsigned)(n_local_px * 3);
         hipLaunchKernelGGL(k_resolve, dim3((n_values + 255) / 256), dim3(256), 0, sc->stream,
-                           (const double*)sc->accum.p, (uint8_t*)sc->rgb.p, n_values);
+                           (const double*)M.accum, (uint8_t*)M.rgb, n_values);
         HIP_TRY(hipEventRecord(gev[2 * G], sc->stream));
         HIP_TRY(hipEventRecord(sc->ev1, sc->stream));
         HIP_TRY(hipGetLastError());
         // The results follow the kernels down the stream before it is known whether a ray queue
         // overflowed (that is rare, and the frame is then rendered and copied again): one wait
         // for kernels, control block and results together.
-        if (rgb_is_device) HIP_TRY(hipMemcpyAsync(rgb_out, sc->rgb.p, (size_t)n_local_px * 3, hipMemcpyDeviceToDevice, sc->stream));
-        else HIP_TRY(hipMemcpyAsync(rgb_out, sc->rgb.p, (size_t)n_local_px * 3, hipMemcpyDeviceToHost, sc->stream));
-        if (hit_ids) HIP_TRY(hipMemcpyAsync(hit_ids, sc->aov.p, (size_t)cam->width * cam->height * sizeof(rtx_hit_id), hipMemcpyDeviceToHost, sc->stream));
-        if (sc->counters_on) HIP_TRY(hipMemcpyAsync(per_gen.data(), sc->counters.p, per_gen.size() * sizeof(Counters), hipMemcpyDeviceToHost, sc->stream));
-        std::vector<GenCtrl> ctrl((size_t)G + 1);
-        HIP_TRY(hipMemcpyAsync(ctrl.data(), sc->ctrl.p, ctrl.size() * sizeof(GenCtrl), hipMemcpyDeviceToHost, sc->stream));
+        if (rgb_is_device) HIP_TRY(hipMemcpyAsync(rgb_out, M.rgb, (size_t)n_local_px * 3, hipMemcpyDeviceToDevice, sc->stream));
+        else HIP_TRY(hipMemcpyAsync(rgb_out, M.rgb, (size_t)n_local_px * 3, hipMemcpyDeviceToHost, sc->stream));
+        if (hit_ids) HIP_TRY(hipMemcpyAsync(hit_ids, M.aov, (size_t)cam->width * cam->height * sizeof(rtx_hit_id), hipMemcpyDeviceToHost, sc->stream));
+        if (sc->counters_on) HIP_TRY(hipMemcpyAsync(sc->h_counters, M.counters, (size_t)G * sizeof(Counters), hipMemcpyDeviceToHost, sc->stream));
+        HIP_TRY(hipMemcpyAsync(sc->h_ctrl, M.ctrl, ctrl_bytes, hipMemcpyDeviceToHost, sc->stream));
         HIP_TRY(hipStreamSynchronize(sc->stream));
+        const GenCtrl* ctrl = sc->h_ctrl;
         float ms = 0.f;
         HIP_TRY(hipEventElapsedTime(&ms, sc->ev0, sc->ev1));
         kernel_ms += ms;
@@ -829,18 +879,21 @@ int rtx_render(rtx_scene* sc, const rtx_camera* cam, int32_t tw, int32_t th, int
                 (void)hipEventElapsedTime(&t_shade, gev[2 * gen + 1], gev[2 * gen + 2]);
                 unsigned long long c = (unsigned long long)n_items0;
                 if (gen > 0) { c = 0; for (const SubCount& sub : ctrl[gen].sub) c += sub.counts; }
-                fprintf(stderr, "[rtx] gen %d: radiance %u shadow %u trace %.1f us tiny-generation trace + shade (+resolve) %.1f us\n", gen,
+                fprintf(stderr, "[rtx] gen %d: radiance %u shadow %u trace %.1f us shade (+resolve) %.1f us\n", gen,
                         (unsigned)c, (unsigned)(c >> 32), t_trace * 1e3, t_shade * 1e3);
             }
         }
-        bool overflow = false;
+        bool overflow = false, limit = false;
         uint32_t peak = 0;
-        for (const GenCtrl& c : ctrl) {
+        for (int k = 0; k <= G; k++) {
+            const GenCtrl& c = ctrl[k];
             overflow |= c.overflow != 0;
+            limit |= c.limit != 0;
             // the fullest sub-queue decides: all sub-queues have the same size
             for (const SubCount& sub : c.sub)
                 peak = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(peak, ((sub.counts & 0xFFFFFFFFull) + (sub.counts >> 32)) * RTX_NSUB), 0x7FFFFFF0ull);
         }
+        if (limit) return fail(RTX_ELIMIT, "a traversal stack or frontier overflowed on the device: the picture would be incomplete");
         if (!overflow) {
             if (stats) {
                 stats->generations = (uint32_t)G;
@@ -849,17 +902,20 @@ int rtx_render(rtx_scene* sc, const rtx_camera* cam, int32_t tw, int32_t th, int
             break;
         }
         overflows++;
+        // (an overflowed generation stops the frame, so `peak` is a lower bound of what is needed: at least double)
         int64_t want = std::max<int64_t>((int64_t)peak + (peak >> 3), (int64_t)sc->queue_capacity * 2);
         sc->queue_capacity = (uint32_t)std::min<int64_t>(want, 0x7FFFFFF0);
         if (overflows > 8) return fail(RTX_ENOMEM, "ray queues kept overflowing");
     }
+    guard.armed = false;
 
+    const Counters* per_gen = sc->h_counters;
     Counters ctr{};
     if (sc->counters_on) {
         static_assert(sizeof(Counters) % sizeof(unsigned long long) == 0, "Counters is an array of u64");
-        for (const Counters& c : per_gen)
+        for (int gen = 0; gen < G; gen++)
             for (size_t k = 0; k < sizeof(Counters) / sizeof(unsigned long long); k++)
-                ((unsigned long long*)&ctr)[k] += ((const unsigned long long*)&c)[k];
+                ((unsigned long long*)&ctr)[k] += ((const unsigned long long*)&per_gen[gen])[k];
         if (getenv("RTX_AMD_GEN_TIMING"))
             for (int gen = 0; gen < G; gen++) {
                 const Counters& c = per_gen[(size_t)gen];
@@ -910,6 +966,15 @@ int rtx_render(rtx_scene* sc, const rtx_camera* cam, int32_t tw, int32_t th, int
         stats->total_ms = std::chrono::duration<double, std::milli>(std::chrono::high_resolution_clock::now() - wall0).count();
     }
     return RTX_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int rtx_render(rtx_scene* sc, const rtx_camera* cam, int32_t tw, int32_t th, int32_t first, int32_t stride,
+               uint8_t* rgb_out, int32_t rgb_is_device, rtx_hit_id* hit_ids, rtx_stats* stats) {
+    return render_frame(sc, cam, tw, th, first, stride, rgb_out, rgb_is_device, hit_ids, stats);
 }
 
 }  // extern "C"

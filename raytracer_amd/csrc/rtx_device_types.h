@@ -130,6 +130,9 @@ struct Scene {
     // box of everything and key of the root record
     double tl_min[3], tl_max[3];
     int32_t tl_key, pad_tl;
+    // Where the traversal reports a full stack or frontier (GenCtrl::limit of the frame's first
+    // control block; set per frame).  Read only at the place that reports, so it costs no register.
+    unsigned* limit_flag;
 };
 
 // Per-frame camera basis, precomputed on the host with the arithmetic of utils.cpp:135-146.
@@ -176,9 +179,15 @@ struct HitBuf { Hit* recs; };
 // the sub-queue and observes the other end's fill level at the same instant.
 #define RTX_NSUB 16
 struct alignas(128) SubCount { unsigned long long counts; unsigned long long pad[15]; };
+// overflow: a reservation in one of this generation's sub-queues did not fit -- the generation's
+// rays are incomplete, its kernels and those of every later generation return at once (the flag is
+// handed on from control block to control block) and the host renders the frame again with
+// larger queues.  limit: a structural limit of the traversal was hit on the device (a lane's
+// stack or a wave's frontier was full and an entry would have been dropped); the host turns it
+// into RTX_ELIMIT instead of returning a picture.
 struct alignas(128) GenCtrl {
     SubCount sub[RTX_NSUB];
-    unsigned head_trace, head_shade, overflow, pad[29];
+    unsigned head_trace, head_shade, overflow, limit, pad[28];
 };
 
 // Everything the kernels of one frame read besides the bulk arrays, kept in device memory so

@@ -18,13 +18,13 @@
 // ballot-compacted reservation (one atomic per wave per child slot), so queues stay dense.
 //
 // Traversal is wave-cooperative.  Each lane walks its own ray through the BVH with its own
-// stack, but the 128-byte node (or 80-byte triangle) records the lanes need are fetched by
-// the whole wave: eight lanes read one record as eight adjacent 16-byte pieces, so one
-// load instruction touches 8 records x 128 contiguous bytes instead of 64 scattered
-// 16-byte pieces.  The loads are LDS-DMA (global_load_lds_dwordx4): the pieces land directly
-// in the owner lane's 128-byte LDS row without passing through registers.
-// Lanes alternate between an inner-node phase and a leaf phase by majority vote
-// (while-while traversal), which keeps each lane's own visit order untouched.  Lanes are
+// stack, but the 256-byte records the lanes need (a four-wide collapsed node, or two 128-byte
+// triangle records of a leaf) are fetched by the whole wave: sixteen lanes read one record as
+// sixteen adjacent 16-byte pieces, so one load instruction touches 4 records x 256 contiguous
+// bytes instead of 64 scattered 16-byte pieces.  The loads are LDS-DMA (global_load_lds_dwordx4):
+// the pieces land directly in the owner lane's 256-byte LDS row without passing through
+// registers.  Inner-node lanes and leaf lanes advance in the same step (both kinds of record
+// come through the same fetch), which keeps each lane's own visit order untouched.  Lanes are
 // refilled dynamically: a lane that finishes its ray (or the current object of its ray) picks
 // up its next job while the other lanes keep traversing (see "Per-lane ray state" below).
 //
@@ -1137,7 +1137,7 @@ struct WideIn { double rox, roy, roz, rdx, rdy, rdz, ix, iy, iz, t_min, stop; in
 struct WideOut { double t_min; int btri, wmin, wmax; };
 
 __device__ __attribute__((noinline)) WideOut wide_job(const Scene& S, const Wave wv, const WideIn L, glob_v4i* stk, unsigned* inst_bits,
-                                                      const unsigned inst_words, const int src) {
+                                                      const int src) {
     const unsigned lane = wv.lane;
     const char* const blas = S.blas;
     const unsigned n_summary = rtx_summary_words(S.n_insts);
@@ -1157,7 +1157,6 @@ __device__ __attribute__((noinline)) WideOut wide_job(const Scene& S, const Wave
                                                        (unsigned)__builtin_amdgcn_readlane((int)stk_a, src));
     unsigned* o_bits = (unsigned*)(size_t)(((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(bits_a >> 32), src) << 32) |
                                            (unsigned)__builtin_amdgcn_readlane((int)bits_a, src));
-    (void)inst_words;
     const bool cull = S.cull != 0;
     const double isect_eps = S.isect_eps;
 
@@ -1298,7 +1297,11 @@ __device__ __attribute__((noinline)) WideOut wide_job(const Scene& S, const Wave
             }
         }
         count += total;
-        if (count > RTX_WIDE_CAP) count = RTX_WIDE_CAP;      // (cannot happen: W leaves room for 4 W pushes)
+        // Cannot happen, so there is nothing to report: while W is computed, count + 3 W stays below
+        // RTX_WIDE_CAP - 104; once W is forced to 1 the wave descends depth-first from the top entry,
+        // which adds at most three entries per record level (at most 26 levels, Launch::wide_ok) plus
+        // one per halving of a long leaf (< 26): fewer than the 104 entries held back.
+        if (count > RTX_WIDE_CAP) count = RTX_WIDE_CAP;
         __builtin_amdgcn_s_waitcnt(0xC07F);
         __builtin_amdgcn_wave_barrier();
         const double m = wave_min_d(best_t);
@@ -1317,7 +1320,7 @@ __device__ __attribute__((noinline)) WideOut wide_job(const Scene& S, const Wave
 }
 
 // Run the jobs of the lanes in `m` wave-wide, one after the other.
-RTX_DEV void wide_jobs(const Scene& S, const Wave& wv, Lane& L, glob_v4i* stk, unsigned* inst_bits, unsigned inst_words,
+RTX_DEV void wide_jobs(const Scene& S, const Wave& wv, Lane& L, glob_v4i* stk, unsigned* inst_bits,
                        unsigned long long m) {
     WideIn in;
     in.rox = L.ro.x; in.roy = L.ro.y; in.roz = L.ro.z; in.rdx = L.rd.x; in.rdy = L.rd.y; in.rdz = L.rd.z;
@@ -1326,7 +1329,7 @@ RTX_DEV void wide_jobs(const Scene& S, const Wave& wv, Lane& L, glob_v4i* stk, u
     while (m != 0ull) {
         const int src = __ffsll((long long)m) - 1;
         m &= m - 1ull;
-        const WideOut out = wide_job(S, wv, in, stk, inst_bits, inst_words, src);
+        const WideOut out = wide_job(S, wv, in, stk, inst_bits, src);
         if ((int)wv.lane == src) {
             if (out.t_min < INFINITY) { L.t_min = out.t_min; L.btri = out.btri; }
             L.word = min(L.word, out.wmin); L.whi = max(L.whi, out.wmax);
@@ -1437,6 +1440,9 @@ RTX_DEV unsigned long long traverse_steps(const Scene& S, const Wave& wv, Lane& 
 #pragma unroll
                 for (int k = 3; k >= 1; k--) {
                     const bool earlier = k == 3 ? any2 : (k == 2 ? any1 : any0);
+                    // (a full stack cannot happen with trees the host has accepted; if it does, the
+                    // frame is reported as failed instead of silently losing a subtree)
+                    if (c[k].ok && earlier && L.sp >= RTX_STACK) *S.limit_flag = 1u;
                     if (c[k].ok && earlier && L.sp < RTX_STACK) {
                         if (L.sp > 0) stk[L.sp - 1] = L.top;
                         L.top.x = __double2loint(c[k].e); L.top.y = __double2hiint(c[k].e); L.top.z = c[k].ref; L.top.w = c[k].cnt;
@@ -1544,6 +1550,10 @@ k_trace(const Launch* __restrict__ Lp, GenCtrl* ctrl, const int gen, double* __r
     wv.lane = lane_id();
     const unsigned lane = wv.lane;
     GenCtrl* me = ctrl + gen;
+    // A generation whose queue overflowed while it was being filled is incomplete, and the slots
+    // its counters claim beyond the queue were never written: it is not traced (k_shade hands the
+    // flag on, so every later generation stops too, and the host renders the frame again).
+    if (gen != 0 && me->overflow != 0u) return;
     GenItems items;
     unsigned n_in;
     if (gen == 0) n_in = (unsigned)F.n_items0;
@@ -1652,7 +1662,7 @@ k_trace(const Launch* __restrict__ Lp, GenCtrl* ctrl, const int gen, double* __r
         if (m_trav == 0ull) break;
         const long long c1 = COUNT ? clock64() : 0;
         const unsigned long long m_wide = traverse_steps<COUNT, WIDE>(S, wv, L, stk, inst_bits, service_threshold, !drained, wide_lanes, wide_age, tl);
-        if (!COUNT && WIDE != 0 && m_wide != 0ull) wide_jobs(S, wv, L, stk, inst_bits, Lp->inst_words, m_wide);
+        if (!COUNT && WIDE != 0 && m_wide != 0ull) wide_jobs(S, wv, L, stk, inst_bits, m_wide);
         if (COUNT) tl.clk_trav += (unsigned long long)(clock64() - c1);
     }
 
@@ -1698,6 +1708,11 @@ k_shade(const Launch* __restrict__ Lp, GenCtrl* ctrl, const int gen, double* __r
     const unsigned lane = lane_id();
     GenCtrl* me = ctrl + gen;
     GenCtrl* next = ctrl + gen + 1;
+    // an overflowed generation was not traced (see k_trace): nothing to shade, and the next one stops too
+    if (gen != 0 && me->overflow != 0u) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) next->overflow = 1u;
+        return;
+    }
     GenItems items;
     unsigned n_in;
     if (gen == 0) n_in = (unsigned)F.n_items0;
