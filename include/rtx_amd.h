@@ -44,7 +44,8 @@ enum {
     RTX_ENOMEM = -4,     /* ray queues would exceed the configured cap  */
     RTX_ELIMIT = -5      /* a structural limit was exceeded: BVH or instance hierarchy deeper than the
                             traversal stack (at creation, or detected on the device while rendering --
-                            no picture is returned then), frame too large for one call */
+                            no picture is returned then), frame too large for one call, fixed scratch
+                            of rtx_render_noalloc too small */
 };
 
 /* Intersection::Kind, in the reference's enum order (scene.h:256). */
@@ -188,6 +189,24 @@ int rtx_render(rtx_scene* scene, const rtx_camera* camera,
                int32_t tile_w, int32_t tile_h, int32_t tile_first, int32_t tile_stride,
                uint8_t* rgb_out, int32_t rgb_is_device,
                rtx_hit_id* hit_ids, rtx_stats* stats);
+
+/* rtx_render for callers that cannot allocate device memory (code under HIP graph capture,
+ * tight serving loops, harnesses that forbid hipMalloc).  It has no counterpart in the
+ * reference.  Same arguments and results as rtx_render (no hit_ids), but every byte of device
+ * memory the frame needs beyond the scene and rgb_out -- ray queues, hit records, traversal
+ * stacks, instance bitmaps, accumulators, control blocks -- comes from one fixed array of
+ * rtx_noalloc_scratch_bytes() bytes (64 MiB) that the library holds on every GPU it runs on until
+ * the process ends; the call makes no hipMalloc / hipFree and its trace grid is 32 blocks, so it
+ * is meant for tiles, not for large frames.  What fits: roughly pixels * (lights + 2) <= 150 000
+ * queued rays (e.g. a 192 x 192 tile with two lights); a larger request fails with RTX_ELIMIT
+ * and a message that states the bytes needed, a queue overflow at run time (deep dielectric
+ * branching) fails with RTX_ENOMEM instead of growing the queues.  Pass page-locked or device
+ * memory as rgb_out (the runtime stages copies into pageable memory itself).  Every call on a
+ * GPU shares that GPU's array: calls that overlap on one GPU, from any scene or thread, race. */
+int rtx_render_noalloc(rtx_scene* scene, const rtx_camera* camera,
+                       int32_t tile_w, int32_t tile_h, int32_t tile_first, int32_t tile_stride,
+                       uint8_t* rgb_out, int32_t rgb_is_device, rtx_stats* stats);
+int64_t rtx_noalloc_scratch_bytes(void);
 
 /* Number of bytes rtx_render writes to rgb_out for the given tiling. */
 int64_t rtx_render_output_bytes(const rtx_camera* camera, int32_t tile_w, int32_t tile_h,

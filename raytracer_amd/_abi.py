@@ -111,6 +111,7 @@ HIT_DTYPE = [("kind", "<i4"), ("container", "<i4"), ("face", "<i4"), ("src", "<i
 
 # Symbols every library must export (checked by the CPU-side ABI test).
 AMD_SYMBOLS = ["rtx_build_bvh", "rtx_scene_create", "rtx_scene_update_lights", "rtx_render",
+               "rtx_render_noalloc", "rtx_noalloc_scratch_bytes",
                "rtx_render_output_bytes", "rtx_unpack_tiles", "rtx_scene_set_counters", "rtx_scene_set_consistent",
                "rtx_scene_set_queue_limit", "rtx_scene_destroy", "rtx_last_error",
                "rtx_device_count"]
@@ -163,6 +164,11 @@ def load_amd_lib():
     lib.rtx_render.argtypes = [C.c_void_p, C.POINTER(Camera), C.c_int32, C.c_int32, C.c_int32,
                                C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.POINTER(Stats)]
     lib.rtx_render.restype = C.c_int
+    lib.rtx_render_noalloc.argtypes = [C.c_void_p, C.POINTER(Camera), C.c_int32, C.c_int32, C.c_int32,
+                                       C.c_int32, C.c_void_p, C.c_int32, C.POINTER(Stats)]
+    lib.rtx_render_noalloc.restype = C.c_int
+    lib.rtx_noalloc_scratch_bytes.argtypes = []
+    lib.rtx_noalloc_scratch_bytes.restype = C.c_int64
     lib.rtx_render_output_bytes.argtypes = [C.POINTER(Camera), C.c_int32, C.c_int32, C.c_int32,
                                             C.c_int32]
     lib.rtx_render_output_bytes.restype = C.c_int64

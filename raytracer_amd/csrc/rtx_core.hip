@@ -93,6 +93,16 @@ struct rtx_scene {
     }
 };
 
+// ---- scratch of the entry point that allocates nothing (rtx_render_noalloc) -------------------
+// One fixed array per GPU, shared by every call on that GPU (calls that overlap on one GPU race).
+// In host code the array's name is only a stand-in: its device address is looked up once per
+// device (rtx_scene_create, with that device current) and only that address is ever used.
+#define RTX_NOALLOC_SCRATCH_BYTES (64u << 20)
+#define RTX_NOALLOC_BLOCKS 32u        // blocks of its trace grid (each lane has a traversal stack in the scratch)
+#define RTX_MAX_DEVICES 64
+static __device__ __align__(256) unsigned char scratch[RTX_NOALLOC_SCRATCH_BYTES];
+static unsigned char* g_scratch_at[RTX_MAX_DEVICES];   // device address of `scratch` on each GPU
+
 namespace {
 
 // ---- BLAS flattening ---------------------------------------------------------------------
@@ -596,6 +606,12 @@ int rtx_scene_create(const rtx_scene_desc* desc, int device, rtx_scene** out) {
         hipDeviceProp_t prop;
         if (e == hipSuccess && hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
             sc->cus = prop.multiProcessorCount;
+        // device address of this GPU's copy of the no-allocation scratch array
+        if (e == hipSuccess && device < RTX_MAX_DEVICES && !g_scratch_at[device]) {
+            unsigned char* at = nullptr;
+            e = hipGetSymbolAddress((void**)&at, HIP_SYMBOL(scratch));
+            if (e == hipSuccess) g_scratch_at[device] = at;
+        }
         if (e != hipSuccess) rc = fail(RTX_EHIP, hipGetErrorString(e));
     }
     if (rc != RTX_OK) { delete sc; return rc; }
@@ -670,7 +686,8 @@ int rtx_unpack_tiles(const uint8_t* packed, int32_t width, int32_t height, int32
 
 namespace {
 
-// Device memory one frame works in.
+// Device memory one frame works in: the library's own growing buffers (rtx_render) or pieces of
+// the fixed scratch array (rtx_render_noalloc).
 struct FrameMem {
     void *accum = nullptr, *rgb = nullptr, *ctrl = nullptr, *counters = nullptr, *aov = nullptr, *stacks = nullptr;
     void *launch = nullptr, *hitbuf = nullptr, *queue[2] = {nullptr, nullptr};
@@ -687,7 +704,7 @@ struct StreamGuard {
 };
 
 int render_frame(rtx_scene* sc, const rtx_camera* cam, int32_t tw, int32_t th, int32_t first, int32_t stride,
-                 uint8_t* rgb_out, int32_t rgb_is_device, rtx_hit_id* hit_ids, rtx_stats* stats) {
+                 uint8_t* rgb_out, int32_t rgb_is_device, rtx_hit_id* hit_ids, rtx_stats* stats, const bool noalloc) {
     if (!sc || !cam || !rgb_out) return fail(RTX_EINVAL, "null argument");
     TileGeom g;
     int rc = tile_geometry(cam, tw, th, first, stride, g);
@@ -741,7 +758,8 @@ int render_frame(rtx_scene* sc, const rtx_camera* cam, int32_t tw, int32_t th, i
 
     const int G = sc->dev.max_depth + 2;
     // One grid of resident blocks: RTX_TRACE_WAVES waves per SIMD = that many 256-thread blocks per CU.
-    const unsigned persistent_blocks = (unsigned)sc->cus * (unsigned)RTX_TRACE_WAVES;
+    unsigned persistent_blocks = (unsigned)sc->cus * (unsigned)RTX_TRACE_WAVES;
+    if (noalloc) persistent_blocks = std::min(persistent_blocks, RTX_NOALLOC_BLOCKS);
     // one bit per instance per lane; every ray leaves its lane's bitmap clear
     const uint32_t inst_words = rtx_bitmap_words(sc->dev.n_insts) + rtx_summary_words(sc->dev.n_insts);
     const size_t accum_bytes = (size_t)n_local_px * 3 * sizeof(double);
@@ -751,21 +769,56 @@ int render_frame(rtx_scene* sc, const rtx_camera* cam, int32_t tw, int32_t th, i
     const int64_t queue_want = std::max<int64_t>(n_local_px * (int64_t)(sc->dev.n_lights + 2), 1 << 12);
 
     FrameMem M;
-    HIP_TRY(sc->accum.ensure(accum_bytes));                     M.accum = sc->accum.p;
-    HIP_TRY(sc->rgb.ensure((size_t)n_local_px * 3));            M.rgb = sc->rgb.p;
-    HIP_TRY(sc->ctrl.ensure(ctrl_bytes));                       M.ctrl = sc->ctrl.p;
-    HIP_TRY(sc->counters.ensure((size_t)G * sizeof(Counters))); M.counters = sc->counters.p;   // one block per generation
-    if (hit_ids) { HIP_TRY(sc->aov.ensure((size_t)cam->width * cam->height * sizeof(rtx_hit_id))); M.aov = sc->aov.p; }
-    HIP_TRY(sc->stacks.ensure(stack_bytes));                    M.stacks = sc->stacks.p;
-    HIP_TRY(sc->launch.ensure(sizeof(Launch)));                 M.launch = sc->launch.p;
-    if (bits_bytes > ((size_t)8 << 30)) return fail(RTX_ELIMIT, "too many instances for the per-lane instance bitmaps");
-    if (bits_bytes > sc->inst_bits.bytes || sc->inst_bits_cleared < bits_bytes) {
-        HIP_TRY(sc->inst_bits.ensure(bits_bytes));
-        HIP_TRY(hipMemsetAsync(sc->inst_bits.p, 0, sc->inst_bits.bytes, sc->stream));    // zeroed once
-        sc->inst_bits_cleared = sc->inst_bits.bytes;
+    if (!noalloc) {
+        HIP_TRY(sc->accum.ensure(accum_bytes));                     M.accum = sc->accum.p;
+        HIP_TRY(sc->rgb.ensure((size_t)n_local_px * 3));            M.rgb = sc->rgb.p;
+        HIP_TRY(sc->ctrl.ensure(ctrl_bytes));                       M.ctrl = sc->ctrl.p;
+        HIP_TRY(sc->counters.ensure((size_t)G * sizeof(Counters))); M.counters = sc->counters.p;   // one block per generation
+        if (hit_ids) { HIP_TRY(sc->aov.ensure((size_t)cam->width * cam->height * sizeof(rtx_hit_id))); M.aov = sc->aov.p; }
+        HIP_TRY(sc->stacks.ensure(stack_bytes));                    M.stacks = sc->stacks.p;
+        HIP_TRY(sc->launch.ensure(sizeof(Launch)));                 M.launch = sc->launch.p;
+        if (bits_bytes > ((size_t)8 << 30)) return fail(RTX_ELIMIT, "too many instances for the per-lane instance bitmaps");
+        if (bits_bytes > sc->inst_bits.bytes || sc->inst_bits_cleared < bits_bytes) {
+            HIP_TRY(sc->inst_bits.ensure(bits_bytes));
+            HIP_TRY(hipMemsetAsync(sc->inst_bits.p, 0, sc->inst_bits.bytes, sc->stream));    // zeroed once
+            sc->inst_bits_cleared = sc->inst_bits.bytes;
+        }
+        M.inst_bits = (unsigned*)sc->inst_bits.p;
+        if (sc->queue_capacity == 0) sc->queue_capacity = (uint32_t)std::min<int64_t>(std::max<int64_t>(queue_want, 1 << 16), 0x7FFFFFF0);
+    } else {
+        // carve the frame's memory out of this GPU's scratch array; nothing is allocated
+        if (hit_ids) return fail(RTX_EINVAL, "the no-allocation entry point returns no hit_ids");
+        unsigned char* const base = sc->device < RTX_MAX_DEVICES ? g_scratch_at[sc->device] : nullptr;
+        if (!base) return fail(RTX_EHIP, "the scratch array's device address is not known for this GPU");
+        size_t at = 0;
+        auto take = [&](size_t n) { unsigned char* p = base + at; at += (n + 255) & ~(size_t)255; return (void*)p; };
+        M.launch = take(sizeof(Launch));
+        M.ctrl = take(ctrl_bytes);
+        M.counters = take((size_t)G * sizeof(Counters));
+        M.accum = take(accum_bytes);
+        M.rgb = take((size_t)n_local_px * 3);
+        M.stacks = take(stack_bytes);
+        M.inst_bits = (unsigned*)take(bits_bytes);
+        // the rest: two ray queues (96 B per ray each) and the hit records (128 B per ray)
+        const int64_t need = std::max<int64_t>(queue_want, n_items0);
+        const int64_t room = (int64_t)RTX_NOALLOC_SCRATCH_BYTES - (int64_t)at;
+        const int64_t cap = room > 0 ? (room / (int64_t)(2 * kRayBytes + kHitBytes)) / RTX_NSUB * RTX_NSUB : 0;
+        if (cap < need || at > RTX_NOALLOC_SCRATCH_BYTES) {
+            char msg[256];
+            snprintf(msg, sizeof msg, "rtx_render_noalloc: %lld pixels with %d lights and %d instances need %lld bytes of scratch, "
+                     "the fixed array has %u; render fewer tiles per call or use rtx_render",
+                     (long long)n_local_px, sc->dev.n_lights, sc->dev.n_insts,
+                     (long long)at + need * (long long)(2 * kRayBytes + kHitBytes), RTX_NOALLOC_SCRATCH_BYTES);
+            return fail(RTX_ELIMIT, msg);
+        }
+        M.queue_capacity = (uint32_t)std::min<int64_t>(cap, 0x7FFFFFF0);
+        M.hit_capacity = (size_t)M.queue_capacity;
+        M.queue[0] = take((size_t)M.queue_capacity * kRayBytes);
+        M.queue[1] = take((size_t)M.queue_capacity * kRayBytes);
+        M.hitbuf = take(M.hit_capacity * kHitBytes);
+        // the array keeps the last call's contents (possibly another scene's): clear the candidate bitmaps
+        HIP_TRY(hipMemsetAsync(M.inst_bits, 0, bits_bytes, sc->stream));
     }
-    M.inst_bits = (unsigned*)sc->inst_bits.p;
-    if (sc->queue_capacity == 0) sc->queue_capacity = (uint32_t)std::min<int64_t>(std::max<int64_t>(queue_want, 1 << 16), 0x7FFFFFF0);
 
     StreamGuard guard{sc->stream};
     uint32_t overflows = 0;
@@ -773,18 +826,20 @@ int render_frame(rtx_scene* sc, const rtx_camera* cam, int32_t tw, int32_t th, i
     uint32_t trace_launches = 0;
     const bool poison = getenv("RTX_AMD_POISON_QUEUES") != nullptr;   // test aid: queues and hit records start as 0xFF
     while (true) {
-        if ((int64_t)sc->queue_capacity * (int64_t)kRayBytes * 2 > sc->queue_limit) {
-            uint32_t cap = (uint32_t)(sc->queue_limit / (2 * (int64_t)kRayBytes));
-            if (overflows > 0 && cap <= sc->queue_capacity / 2 + 1)
-                return fail(RTX_ENOMEM, "ray queues exceed the configured limit; render fewer tiles per call or raise the limit");
-            sc->queue_capacity = cap;
+        if (!noalloc) {
+            if ((int64_t)sc->queue_capacity * (int64_t)kRayBytes * 2 > sc->queue_limit) {
+                uint32_t cap = (uint32_t)(sc->queue_limit / (2 * (int64_t)kRayBytes));
+                if (overflows > 0 && cap <= sc->queue_capacity / 2 + 1)
+                    return fail(RTX_ENOMEM, "ray queues exceed the configured limit; render fewer tiles per call or raise the limit");
+                sc->queue_capacity = cap;
+            }
+            HIP_TRY(sc->queue[0].ensure((size_t)sc->queue_capacity * kRayBytes));
+            HIP_TRY(sc->queue[1].ensure((size_t)sc->queue_capacity * kRayBytes));
+            M.hit_capacity = std::max<size_t>(sc->queue_capacity, (size_t)n_items0);
+            HIP_TRY(sc->hitbuf.ensure(M.hit_capacity * kHitBytes));
+            M.queue[0] = sc->queue[0].p; M.queue[1] = sc->queue[1].p; M.hitbuf = sc->hitbuf.p;
+            M.queue_capacity = sc->queue_capacity;
         }
-        HIP_TRY(sc->queue[0].ensure((size_t)sc->queue_capacity * kRayBytes));
-        HIP_TRY(sc->queue[1].ensure((size_t)sc->queue_capacity * kRayBytes));
-        M.hit_capacity = std::max<size_t>(sc->queue_capacity, (size_t)n_items0);
-        HIP_TRY(sc->hitbuf.ensure(M.hit_capacity * kHitBytes));
-        M.queue[0] = sc->queue[0].p; M.queue[1] = sc->queue[1].p; M.hitbuf = sc->hitbuf.p;
-        M.queue_capacity = sc->queue_capacity;
         if (poison) {
             HIP_TRY(hipMemsetAsync(M.queue[0], 0xFF, (size_t)M.queue_capacity * kRayBytes, sc->stream));
             HIP_TRY(hipMemsetAsync(M.queue[1], 0xFF, (size_t)M.queue_capacity * kRayBytes, sc->stream));
@@ -902,6 +957,12 @@ int render_frame(rtx_scene* sc, const rtx_camera* cam, int32_t tw, int32_t th, i
             break;
         }
         overflows++;
+        if (noalloc) {
+            char msg[200];
+            snprintf(msg, sizeof msg, "rtx_render_noalloc: the ray queues (%u rays each, fixed scratch) overflowed; "
+                     "render fewer tiles per call or use rtx_render", M.queue_capacity);
+            return fail(RTX_ENOMEM, msg);
+        }
         // (an overflowed generation stops the frame, so `peak` is a lower bound of what is needed: at least double)
         int64_t want = std::max<int64_t>((int64_t)peak + (peak >> 3), (int64_t)sc->queue_capacity * 2);
         sc->queue_capacity = (uint32_t)std::min<int64_t>(want, 0x7FFFFFF0);
@@ -974,7 +1035,14 @@ extern "C" {
 
 int rtx_render(rtx_scene* sc, const rtx_camera* cam, int32_t tw, int32_t th, int32_t first, int32_t stride,
                uint8_t* rgb_out, int32_t rgb_is_device, rtx_hit_id* hit_ids, rtx_stats* stats) {
-    return render_frame(sc, cam, tw, th, first, stride, rgb_out, rgb_is_device, hit_ids, stats);
+    return render_frame(sc, cam, tw, th, first, stride, rgb_out, rgb_is_device, hit_ids, stats, false);
 }
+
+int rtx_render_noalloc(rtx_scene* sc, const rtx_camera* cam, int32_t tw, int32_t th, int32_t first, int32_t stride,
+                       uint8_t* rgb_out, int32_t rgb_is_device, rtx_stats* stats) {
+    return render_frame(sc, cam, tw, th, first, stride, rgb_out, rgb_is_device, nullptr, stats, true);
+}
+
+int64_t rtx_noalloc_scratch_bytes(void) { return (int64_t)RTX_NOALLOC_SCRATCH_BYTES; }
 
 }  // extern "C"

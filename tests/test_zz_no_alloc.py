@@ -1,0 +1,77 @@
+"""rtx_render_noalloc (the entry point that allocates no device memory: every buffer of the
+frame comes from one fixed array per GPU) against rtx_render, through the C-ABI: two calls
+in a row, the second with a smaller input, each compared with the allocating entry point."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import _checkers as ck
+import raytracer_amd as rt
+from raytracer_amd import _abi, scenes
+
+pytestmark = pytest.mark.gpu
+
+
+def _noalloc(lib, ds, cam, tw, th, first, stride):
+    n = lib.rtx_render_output_bytes(C.byref(cam), tw, th, first, stride)
+    out = np.full(n, 0xAB, dtype=np.uint8)
+    st = _abi.Stats()
+    rc = lib.rtx_render_noalloc(ds._h, C.byref(cam), tw, th, first, stride, out.ctypes.data, 0, C.byref(st))
+    return rc, out, st.as_dict()
+
+
+def test_noalloc_matches_render_on_two_calls_in_a_row(tmp_path):
+    lib = rt.amd_lib()
+    assert lib.rtx_noalloc_scratch_bytes() == 64 << 20
+    # first call: an instanced scene (TLAS walk, instance bitmaps in the scratch), whole frame
+    big = scenes.scene_grass(str(tmp_path), n_instances=300, res=(160, 120), name="na_grass")
+    hs1 = rt.HostScene(big)
+    ds1 = rt.DeviceScene(hs1.desc, 0)
+    cam1, _ = hs1.camera(0)
+    ref1, _, _ = ds1.render(cam1)
+    rc, out1, st1 = _noalloc(lib, ds1, cam1, cam1.width, cam1.height, 0, 1)
+    assert rc == 0, lib.rtx_last_error()
+    same, mx = ck.image_diff(out1.reshape(ref1.shape), ref1)
+    assert mx <= 2 and same >= 0.999, (same, mx)
+    o_rgb, _, _, _ = ck.oracle_render(hs1.desc, cam1, want_hits=False)
+    same, mx = ck.image_diff(out1.reshape(ref1.shape), o_rgb)
+    assert mx <= 2 and same >= 0.999, (same, mx)
+    # second call, smaller input, another scene: every third 16x8 tile of a 64x48 frame
+    small = scenes.scene_tiny(str(tmp_path), res=(64, 48))
+    hs2 = rt.HostScene(small)
+    ds2 = rt.DeviceScene(hs2.desc, 0)
+    cam2, _ = hs2.camera(0)
+    ref2, _ = ds2.render_tiles(cam2, 16, 8, 1, 3)
+    rc, out2, st2 = _noalloc(lib, ds2, cam2, 16, 8, 1, 3)
+    assert rc == 0, lib.rtx_last_error()
+    assert out2.size == ref2.size
+    d = np.abs(out2.astype(np.int16) - ref2.astype(np.int16))
+    assert d.max() <= 2 and (d.reshape(-1, 3).max(axis=1) == 0).mean() >= 0.999
+    # and the first scene again through the same array: what the second call left behind does not matter
+    rc, out3, _ = _noalloc(lib, ds1, cam1, cam1.width, cam1.height, 0, 1)
+    assert rc == 0
+    same, mx = ck.image_diff(out3.reshape(ref1.shape), ref1)
+    assert mx <= 2 and same >= 0.999, (same, mx)
+    for x in (ds1, ds2):
+        x.close()
+    hs1.close(); hs2.close()
+
+
+def test_noalloc_rejects_what_does_not_fit(tmp_path):
+    lib = rt.amd_lib()
+    path = scenes.scene_tiny(str(tmp_path), res=(1024, 1024))
+    hs = rt.HostScene(path)
+    ds = rt.DeviceScene(hs.desc, 0)
+    cam, _ = hs.camera(0)
+    rc, _, _ = _noalloc(lib, ds, cam, cam.width, cam.height, 0, 1)
+    assert rc == -5
+    msg = lib.rtx_last_error().decode()
+    assert "rtx_render_noalloc" in msg and "bytes of scratch" in msg
+    # one 128 x 128 tile of the same frame fits
+    rc, out, _ = _noalloc(lib, ds, cam, 128, 128, 27, 64)
+    assert rc == 0, lib.rtx_last_error()
+    ref, _ = ds.render_tiles(cam, 128, 128, 27, 64)
+    d = np.abs(out.astype(np.int16) - ref.astype(np.int16))
+    assert d.max() <= 2 and (d.reshape(-1, 3).max(axis=1) == 0).mean() >= 0.999
+    ds.close(); hs.close()
