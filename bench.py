@@ -1,19 +1,31 @@
 #!/usr/bin/env python3
-"""Benchmark of the hot path: one step = one frame of the workload through rtx_render.
+"""Benchmark of the hot path: one step = one frame per GPU through rtx_render.
 
-Metric: Mrays/s and ms/frame.  A ray is one closest-hit query the reference
-semantics require (one intersect() call, utils.cpp:671, not counting calls whose result
-computePixelColor discards); the per-frame ray count R is taken from the device's own
-counters in an untimed pass and is, by construction and by test, the count the CPU
-restatement produces.
+Metric: Mrays/s and ms/frame.  A ray is one closest-hit query the reference semantics require
+(one intersect() call, utils.cpp:671, not counting calls whose result computePixelColor
+discards); the per-frame ray count is taken from the device's own counters in an untimed pass
+and is, by construction and by test, the count the CPU restatement produces.
 
-N = 1: the dragon_metal stand-in (one 1.8 M-face smooth conductor mesh + a Lambertian
-instance of it + ground, 1920x1152, depth 6) unless --workload says otherwise.
-N > 1: whole frames are sharded -- rank r renders orbit frame r of the same scene every
-step, no collective on the data path (weak scaling); `--mode tiles` instead splits ONE
-frame into interleaved tiles and gathers them on rank 0 over RCCL (strong scaling).
+    python bench.py --gpus N --steps K --warmup W [--workload NAME] [--mode frames|tiles]
 
-Prints one JSON line on rank 0.
+N > 1 without WORLD_SIZE in the environment: this process starts N ranks of itself (one per
+GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, before anything touches a GPU), relays
+rank 0's JSON line and exits with the first failing rank's code.  Under torchrun
+(WORLD_SIZE set) it is one of the ranks.
+
+Workloads and how they shard (the scene is replicated on every GPU, no ray leaves its GPU):
+  dragon_metal (default), marching_dragons, metal_glass_plates, grass_desert, mode frames:
+      rank r renders frame r of an orbit around the scene every step -- whole frames, no
+      collective on the data path (weak scaling).
+  camera_around_david: the 360-frame sequence itself; rank r renders frames r, r+N, ... through
+      the animation pipeline (HostScene.load_next keeps the geometry, update_lights); one step
+      = one frame per rank (weak scaling).
+  --mode tiles (grass_desert at 4K by default): ONE frame split into interleaved tiles, one
+      gather to rank 0 over RCCL (raytracer_amd.distributed.gather_tiled_frame), strong scaling.
+Unless --no-extras is given, the default run also measures the other two shardings after the
+main measurement and reports them as "sequence" and "tiled_frame" inside the same line.
+
+Prints ONE JSON line on rank 0.
 """
 from __future__ import annotations
 
@@ -23,6 +35,7 @@ import json
 import math
 import os
 import shutil
+import socket
 import subprocess
 import sys
 import tempfile
@@ -31,31 +44,142 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import numpy as np  # noqa: E402
-
-# Algorithmic traffic of one frame, in the reference's own in-memory record sizes: what the
-# reference's traversal has to read per unit of work, whatever layout the device uses.
-#   72 B  one BVH node whose box is tested           (sizeof(BVHNode), bvh.h:50-61)
-#   88 B  one triangle test                          (4 B faceIndices + 12 B face + 3 x 24 B vertices)
-#   48 B  one world-space AABB test                  (AABB, bvh.h:11-16)
-#  128 B  one ray taken to object space              (one Matrix4x4, scene.h:123-128)
-#  384 B  one accepted back-transformed hit          (three Matrix4x4)
-#   96 B  per ray                                    (ray in + hit record out)
-# The work counts are those of the reference's algorithm, produced by its CPU restatement
-# (oracle/rt_oracle.c) in an untimed pass; the device's own ray and triangle-test counters must
-# agree with them (reported as "counters_agree").
-HBM_PEAK_GBS = 8000.0
+HBM_PEAK_GBS = 8000.0        # HBM3E, spec
+L2_PEAK_GBS = 34500.0        # 8 x 4 MiB L2, aggregate
+FP64_VALU_PEAK_TF = 78.6     # vector FP64 (what the path computes in)
+FP32_VALU_PEAK_TF = 157.3    # vector FP32
+SEQUENCE_FRAMES = 360
 
 
+# ---------------------------------------------------------------------------------------------
+# Launching the ranks
+# ---------------------------------------------------------------------------------------------
+def free_port() -> int:
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_ranks(n: int, argv, script=None, python=None, extra_env=None) -> int:
+    """Start n ranks of `script` (default: this file) as fresh child processes and wait for
+    them.  Rank 0's stdout is relayed to ours; the other ranks' stdout goes to stderr.  Returns 0
+    when every rank succeeded, otherwise the first non-zero exit code seen (the remaining ranks
+    are then terminated: they would wait in a collective forever).  The parent never touches a
+    GPU, and no process that has is ever replaced by another program."""
+    script = script or os.path.abspath(__file__)
+    python = python or sys.executable
+    port = free_port()
+    procs = []
+    for r in range(n):
+        env = os.environ.copy()
+        env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n), "LOCAL_WORLD_SIZE": str(n),
+                    "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+        env.update(extra_env or {})
+        procs.append(subprocess.Popen([python, script] + list(argv), env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr))
+    rc = 0
+    pending = set(range(n))
+    while pending:
+        for r in sorted(pending):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            pending.discard(r)
+            if code != 0 and rc == 0:
+                rc = code
+                print(f"[bench] rank {r} exited with code {code}; stopping the other ranks", file=sys.stderr, flush=True)
+                for q in pending:
+                    procs[q].terminate()
+        if pending:
+            time.sleep(0.05)
+    out = procs[0].stdout.read().decode(errors="replace")
+    sys.stdout.write(out)
+    sys.stdout.flush()
+    return rc
+
+
+def selftest_rank(args) -> int:
+    """--selftest-ranks: what a rank does when only the launch path is being checked (no GPU):
+    rendezvous over gloo, one all-reduce, rank 0 prints a line with the world size."""
+    import torch
+    import torch.distributed as dist
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.selftest_fail_rank == rank:
+        return 7
+    if world > 1:
+        dist.init_process_group("gloo")
+    t = torch.tensor([float(rank + 1)])
+    if world > 1:
+        dist.all_reduce(t)
+    if rank == 0:
+        print(json.dumps({"selftest": True, "n_gpus": world, "rank_sum": float(t.item()),
+                          "local_rank_env": os.environ.get("LOCAL_RANK")}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0
+
+
+# ---------------------------------------------------------------------------------------------
+# Work counts, algorithmic bytes and flops
+# ---------------------------------------------------------------------------------------------
 class OracleCounters(C.Structure):
     _fields_ = [(k, C.c_uint64) for k in ("rays", "primary_rays", "shadow_rays", "secondary_rays", "node_pops",
                                           "tri_tests", "world_box_tests", "ray_transforms", "transformed_hits",
-                                          "shades")]
+                                          "shades", "tri_past_det", "tri_past_beta", "tri_past_gamma")]
 
 
-def algorithmic_bytes(c) -> int:
+def reference_bytes(c) -> int:
+    """Algorithmic traffic of one frame in the reference's own in-memory record sizes: what the
+    reference's traversal has to read per unit of work, whatever layout the device uses.
+       72 B  one BVH node whose box is tested           (sizeof(BVHNode), bvh.h:50-61)
+       88 B  one triangle test                          (4 B faceIndices + 12 B face + 3 x 24 B vertices)
+       48 B  one world-space AABB test                  (AABB, bvh.h:11-16)
+      128 B  one ray taken to object space              (one Matrix4x4, scene.h:123-128)
+      384 B  one accepted back-transformed hit          (three Matrix4x4)
+       96 B  per ray                                    (ray in + hit record out)"""
     return (72 * c["node_pops"] + 88 * c["tri_tests"] + 48 * c["world_box_tests"] + 128 * c["ray_transforms"]
             + 384 * c["transformed_hits"] + 96 * c["rays"])
+
+
+def device_bytes(st) -> int:
+    """The same frame in the device's own records, from its own counters (counters on: every
+    test of the reference is carried out): a 256-byte four-wide node record per BLAS or TLAS
+    record visit, a 128-byte triangle record per triangle test, the 128 bytes of an object
+    record that hold its world and root boxes per world-box test, the 128-byte inverse matrix
+    per ray taken to object space, 96 bytes of ray record in and 128 bytes of hit record out
+    per ray (shadow rays write no record)."""
+    radiance = st["rays"] - st["shadow_rays"]
+    return (256 * (st["node_visits"] + st["tlas_node_visits"]) + 128 * st["tri_tests"] + 128 * st["world_box_tests"]
+            + 128 * st["object_space_traversals"] + 96 * (st["rays"] - st["primary_rays"]) + 128 * radiance)
+
+
+# FP64 operations of the device's own arithmetic, counted from raytracer_amd/csrc/rtx_kernels.h
+# (adds, multiplies, min/max and compares count one each, a division or square root one):
+#   box_enter_nopar: 6 sub + 6 mul + 6 min/max of pairs + 3 max (entry) + 2 min (exit) + 2 compares = 25;
+#       a four-wide record visit tests four boxes = 100
+#   tri_test: to the determinant guard 3 (o - a) + 9 (e2 x d) + 6 (det) + 1 = 19; then the division,
+#       detB (6), beta and its compares = +10; r x d (9), detG (6), gamma, compares = +20;
+#       e2 x r (9), detT (5), t, compares = +17 (66 for a test that reaches the end)
+#   job set-up of a transformed object (xf_point 25, xf_dir 15, normalize_f32 10, 3 divisions) = 53, its box 25
+#   k_shade: about 150 per shaded hit (normals, Fresnel, children) + 60 per light (shadow-ray set-up, Blinn-Phong)
+def frame_flops(st, ref_counts) -> float:
+    visits = st["node_visits"] + st["tlas_node_visits"]
+    f = 100.0 * visits + 25.0 * st["world_box_tests"] + 53.0 * st["object_space_traversals"]
+    if ref_counts is not None and ref_counts.get("tri_tests"):
+        # stage counts of the reference's algorithm (same tests, same arithmetic), scaled to the device's test count
+        k = st["tri_tests"] / ref_counts["tri_tests"]
+        f += k * (19.0 * ref_counts["tri_tests"] + 10.0 * ref_counts["tri_past_det"] + 20.0 * ref_counts["tri_past_beta"]
+                  + 17.0 * ref_counts["tri_past_gamma"])
+        f += 150.0 * ref_counts["shades"]
+    else:
+        f += 40.0 * st["tri_tests"]
+    f += 60.0 * st["shadow_rays"]
+    return f
 
 
 def cpu_sample_factor(desc, cam) -> int:
@@ -77,32 +201,43 @@ def reduced_camera(cam, f: int):
     return out
 
 
-def reference_work_counts(desc, cam, nthreads):
-    """Work counters of the reference's algorithm for one frame, from its CPU restatement
-    (untimed; None when the checker library is not built)."""
+def oracle_frame(desc, cam, nthreads, want_hits=False):
+    """One frame through the CPU restatement of the reference (oracle/librt_oracle.so, the
+    checker): -> (work counts, rgb, hit records or None, ms), or (None,)*4 when it is not built."""
+    import numpy as np
     so = os.path.join(ROOT, "oracle", "librt_oracle.so")
     if not os.path.exists(so):
-        return None, None
+        return None, None, None, None
     from raytracer_amd import _abi
     lib = C.CDLL(so)
     lib.rt_oracle_render.argtypes = [C.POINTER(_abi.SceneDesc), C.POINTER(_abi.Camera), C.c_void_p, C.c_void_p,
                                      C.POINTER(OracleCounters), C.c_int]
     lib.rt_oracle_render.restype = C.c_double
     rgb = np.empty((cam.height, cam.width, 3), dtype=np.uint8)
+    hits = np.empty(cam.height * cam.width, dtype=_abi.HIT_DTYPE) if want_hits else None
     ctr = OracleCounters()
-    ms = lib.rt_oracle_render(desc, C.byref(cam), rgb.ctypes.data, None, C.byref(ctr), nthreads)
+    ms = lib.rt_oracle_render(desc, C.byref(cam), rgb.ctypes.data, hits.ctypes.data if want_hits else None,
+                              C.byref(ctr), nthreads)
     if ms < 0:
-        return None, None
-    return {k: int(getattr(ctr, k)) for k, _ in OracleCounters._fields_}, ms
+        return None, None, None, None
+    return {k: int(getattr(ctr, k)) for k, _ in OracleCounters._fields_}, rgb, hits, ms
 
 
+def reference_work_counts(desc, cam, nthreads):
+    counts, _, _, ms = oracle_frame(desc, cam, nthreads)
+    return counts, ms
+
+
+# ---------------------------------------------------------------------------------------------
+# Workloads
+# ---------------------------------------------------------------------------------------------
 def scene_cache_dir():
     d = os.environ.get("RTX_BENCH_SCENES", os.path.join(tempfile.gettempdir(), f"rtx_bench_scenes_{os.getuid()}"))
     os.makedirs(d, exist_ok=True)
     return d
 
 
-def make_workload(name: str, d: str, frame: int = 0, n_frames: int = 360):
+def make_workload(name: str, d: str, frame: int = 0, n_frames: int = SEQUENCE_FRAMES):
     """-> (scene json path, description string)"""
     from raytracer_amd import scenes
     if name == "dragon_metal":
@@ -125,17 +260,31 @@ def make_workload(name: str, d: str, frame: int = 0, n_frames: int = 360):
         if not os.path.exists(p):
             scenes.scene_grass(d, n_instances=10_000, res=(3840, 2160), name="grass_desert")
         return p, "grass_desert stand-in: 10k instanced blade clumps, 3840x2160"
+    if name == "grass_small":
+        p = os.path.join(d, "grass_small.json")
+        if not os.path.exists(p):
+            scenes.scene_grass(d, n_instances=400, res=(320, 180), name="grass_small")
+        return p, "grass_desert stand-in, reduced: 400 instances, 320x180"
     if name == "metal_glass_plates":
         p = os.path.join(d, "metal_glass_plates.json")
         if not os.path.exists(p):
             scenes.scene_plates(d, res=(800, 800), name="metal_glass_plates")
         return p, "metal_glass_plates stand-in: plane, spheres, dielectric boxes of free triangles, 800x800"
-    if name == "camera_around_david":
-        p = os.path.join(d, f"davids_camera_{frame:03d}.json")
+    if name in ("camera_around_david", "camera_around_david_small"):
+        small = name.endswith("_small")
+        stem = "davids_small" if small else "davids_camera"
+        p = os.path.join(d, f"{stem}_{frame:03d}.json")
         if not os.path.exists(p):
-            scenes.scene_david_frame(d, frame, n_frames=n_frames, faces=100_000, res=(800, 800), name="davids_camera")
-        return p, "camera_around_david stand-in: 100k-face mesh + mirror ground, 800x800, 360-frame orbit"
+            scenes.scene_david_frame(d, frame, n_frames=n_frames, faces=4_000 if small else 100_000,
+                                     res=(160, 160) if small else (800, 800), name=stem)
+        return p, (f"camera_around_david stand-in{' (reduced)' if small else ''}: "
+                   f"{'4k' if small else '100k'}-face mesh + mirror ground, {'160x160' if small else '800x800'}, "
+                   f"{n_frames}-frame orbit")
     raise SystemExit(f"unknown workload {name}")
+
+
+def is_sequence(name: str) -> bool:
+    return name.startswith("camera_around_david")
 
 
 def orbit_camera(cam, angle_deg: float):
@@ -177,45 +326,471 @@ def reduced_scene_file(scene_json: str, f: int) -> str:
     return out
 
 
-def cpu_reference_baseline(scene_json: str, rays: int, sample_f: int = 1):
+def read_ppm(path):
+    """ASCII P3 file (scene.cpp:686-695) -> uint8 [h][w][3]."""
+    import numpy as np
+    with open(path, "rb") as f:
+        tok = f.read().split()
+    if tok[0] != b"P3":
+        raise ValueError("not a P3 file")
+    w, h = int(tok[1]), int(tok[2])
+    return np.array(tok[4:4 + w * h * 3], dtype=np.int32).astype(np.uint8).reshape(h, w, 3)
+
+
+def cpu_reference_baseline(scene_json: str, rays: int, sample_f: int = 1, runs: int = 3):
     """Time the unmodified reference renderer (oracle/_ref/raytracer_ref, built from the
     reference's own sources) on this host: `./raytracer <scene> -b`, multithreaded default
     = min(4, nproc) threads (raytracer.cpp:99-100).  Reads renderTimeMs from its results
-    JSON (raytracer.cpp:269-282).  sample_f > 1: bounded sample, see cpu_sample_factor."""
+    JSON (raytracer.cpp:269-282); median of `runs` runs.  sample_f > 1: bounded sample, see
+    cpu_sample_factor.  -> (cpu_baseline object, the picture the reference wrote) or (None, None)."""
     ref = os.path.join(ROOT, "oracle", "_ref", "raytracer_ref")
     if not os.access(ref, os.X_OK):
-        return None
+        return None, None
     work = tempfile.mkdtemp(prefix="rtx_ref_")
     try:
         os.makedirs(os.path.join(work, "run"))
-        os.makedirs(os.path.join(work, "my_outputs_hw2"))
+        out_dir = os.path.join(work, "my_outputs_hw2")
+        os.makedirs(out_dir)
         if sample_f > 1:
             scene_json = reduced_scene_file(scene_json, sample_f)
-        t0 = time.time()
-        r = subprocess.run([ref, scene_json, "-b"], cwd=os.path.join(work, "run"), stdout=subprocess.DEVNULL,
-                           stderr=subprocess.DEVNULL, timeout=900)
-        wall = time.time() - t0
-        if r.returncode != 0:
-            return None
-        res = [f for f in os.listdir(os.path.join(work, "my_outputs_hw2")) if f.endswith("_results.json")]
-        if not res:
-            return None
-        with open(os.path.join(work, "my_outputs_hw2", res[0])) as f:
-            j = json.load(f)
-        render_ms = float(j["renderTimeMs"]) * sample_f * sample_f
-        sample = "whole frame once" if sample_f == 1 else \
+        times, pre, walls = [], [], []
+        image = None
+        for _ in range(max(1, runs)):
+            for fn in os.listdir(out_dir):
+                os.remove(os.path.join(out_dir, fn))
+            t0 = time.time()
+            r = subprocess.run([ref, scene_json, "-b"], cwd=os.path.join(work, "run"), stdout=subprocess.DEVNULL,
+                               stderr=subprocess.DEVNULL, timeout=900)
+            walls.append(time.time() - t0)
+            if r.returncode != 0:
+                return None, None
+            res = [f for f in os.listdir(out_dir) if f.endswith("_results.json")]
+            if not res:
+                return None, None
+            with open(os.path.join(out_dir, res[0])) as f:
+                j = json.load(f)
+            times.append(float(j["renderTimeMs"]))
+            pre.append(float(j["preprocessingTimeMs"]))
+            if sum(walls) > 60.0:
+                break
+        ppm = [f for f in os.listdir(out_dir) if f.endswith(".ppm")]
+        if ppm:
+            try:
+                image = read_ppm(os.path.join(out_dir, ppm[0]))
+            except Exception:
+                image = None
+        times_sorted = sorted(times)
+        render_ms = times_sorted[len(times_sorted) // 2] * sample_f * sample_f
+        sample = "whole frame" if sample_f == 1 else \
             f"the same view at 1/{sample_f} of the resolution in both directions, time scaled by {sample_f * sample_f}"
         return {"value": rays / render_ms / 1e3, "unit": "Mrays/s", "cores": min(4, os.cpu_count() or 4),
-                "kind": "reference", "ms_per_frame": render_ms, "preprocess_ms": float(j["preprocessingTimeMs"]),
-                "host_cpus": os.cpu_count(),
-                "sample": f"{sample}, ./raytracer <scene> -b (reference caps itself at 4 threads); process wall {wall:.1f} s"}
+                "kind": "reference", "ms_per_frame": render_ms, "runs_ms": [t * sample_f * sample_f for t in times],
+                "preprocess_ms": sorted(pre)[len(pre) // 2], "host_cpus": os.cpu_count(),
+                "sample": f"{sample}, median of {len(times)} runs of ./raytracer <scene> -b (the reference caps itself at "
+                          f"4 threads); process wall {sum(walls):.1f} s in total"}, image
     except Exception:
-        return None
+        return None, None
     finally:
         shutil.rmtree(work, ignore_errors=True)
 
 
-def main():
+def image_delta(a, b):
+    import numpy as np
+    d = np.abs(a.astype(np.int16) - b.astype(np.int16))
+    return {"identical": float((d.reshape(-1, 3).max(axis=1) == 0).mean()), "max_delta": int(d.max()) if d.size else 0}
+
+
+def hit_mismatches(a, b) -> int:
+    import numpy as np
+    bad = (a["kind"] != b["kind"]) | (a["container"] != b["container"]) | (a["face"] != b["face"]) | (a["src"] != b["src"])
+    bad |= a["distance"].view(np.uint64) != b["distance"].view(np.uint64)
+    return int(bad.sum())
+
+
+# ---------------------------------------------------------------------------------------------
+# One rank
+# ---------------------------------------------------------------------------------------------
+class Rank:
+    def __init__(self, args):
+        import torch
+        self.torch = torch
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        if self.world != args.gpus:
+            raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={self.world}: start bench.py without WORLD_SIZE "
+                             f"(it launches its own ranks) or under a launcher with {args.gpus} ranks")
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a GPU: there is no CPU path behind the C-ABI")
+        # Rehearsal on a one-GPU box (RTX_BENCH_REHEARSAL=1): every rank uses device 0 and the
+        # collectives run over gloo on host tensors; everything else is the multi-GPU code path.
+        self.rehearsal = os.environ.get("RTX_BENCH_REHEARSAL") == "1"
+        if self.rehearsal:
+            self.local_rank = 0
+        elif self.local_rank >= torch.cuda.device_count():
+            raise SystemExit(f"rank {self.rank}: local rank {self.local_rank} but {torch.cuda.device_count()} GPU(s) visible "
+                             "(set RTX_BENCH_REHEARSAL=1 to rehearse several ranks on one GPU)")
+        torch.cuda.set_device(self.local_rank)
+        self.red_dev = "cpu" if self.rehearsal else "cuda"
+        self.dist = None
+        if self.world > 1:
+            import torch.distributed as dist
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            if self.rehearsal:
+                dist.init_process_group("gloo")
+            else:
+                dist.init_process_group("nccl", device_id=torch.device("cuda", self.local_rank))
+            self.dist = dist
+        self.host_threads = max(1, min(16, os.cpu_count() or 1) // max(self.world, 1))
+
+    def barrier(self):
+        if self.dist is not None:
+            self.dist.barrier()
+        self.torch.cuda.synchronize()
+
+    def note(self, msg):
+        if self.rank == 0:
+            print(f"[bench] {msg}", file=sys.stderr, flush=True)
+
+    def reduce(self, values, op="sum"):
+        t = self.torch.tensor([float(v) for v in values], dtype=self.torch.float64, device=self.red_dev)
+        if self.dist is not None:
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX if op == "max" else self.dist.ReduceOp.SUM)
+        return [float(x) for x in t.tolist()]
+
+    def workload(self, name, frames=(0,)):
+        """Scene files are generated once, by rank 0, into the shared cache directory."""
+        d = scene_cache_dir()
+        if self.rank == 0:
+            for f in frames:
+                make_workload(name, d, f)
+        self.barrier()
+        return [make_workload(name, d, f) for f in frames]
+
+    def pinned(self, nbytes):
+        return self.torch.empty(nbytes, dtype=self.torch.uint8).pin_memory().numpy()
+
+    def close(self):
+        if self.dist is not None:
+            self.dist.barrier()
+            self.dist.destroy_process_group()
+
+
+def timed(R: Rank, step, steps, warmup):
+    """warmup untimed steps, then exactly `steps` steps between barrier + synchronize on both
+    sides -> (elapsed seconds, max over ranks; list of the steps' rtx_stats)."""
+    for i in range(warmup):
+        step(i - warmup)
+    R.barrier()
+    t0 = time.perf_counter()
+    stats = [step(i) for i in range(steps)]
+    R.barrier()
+    elapsed = time.perf_counter() - t0
+    return R.reduce([elapsed], "max")[0], stats
+
+
+def pmc_summary(workload):
+    """Hardware-counter figures of the trace kernel from the committed profile of this workload
+    (profiles/r02_<workload>_pmc.json, written by tools/pmc_to_json.py from separate rocprofv3
+    --pmc passes over this same bench), or None."""
+    p = os.path.join(ROOT, "profiles", f"r02_{workload}_pmc.json")
+    try:
+        with open(p) as f:
+            return json.load(f)
+    except Exception:
+        return None
+
+
+def measure_static(R: Rank, args, name, mode, steps, warmup, with_cpu):
+    """Workloads with one scene file.  mode frames: rank r renders orbit frame r every step.
+    mode tiles: all ranks render interleaved tiles of ONE frame, gathered on rank 0."""
+    import numpy as np
+    import raytracer_amd as rt
+    from raytracer_amd import distributed as D
+    (path, descr), = R.workload(name)
+    R.note(f"workload {name} ({mode}): loading scene")
+    t0 = time.time()
+    hs = rt.HostScene(path)
+    t_load = time.time() - t0
+    t0 = time.time()
+    ds = rt.DeviceScene(hs.desc, R.local_rank)
+    t_upload = time.time() - t0
+    cam0, _ = hs.camera(0)
+    tw, th = (int(x) for x in args.tile.split("x"))
+    world, rank = R.world, R.rank
+    cam = orbit_camera(cam0, 360.0 * rank / world) if (mode == "frames" and world > 1) else cam0
+
+    # ---- untimed counting pass: rays and traversal work of this rank's step ----------------
+    R.note("device counting pass")
+    ds.set_counters(True)
+    if mode == "frames":
+        _, _, cst = ds.render(cam)
+    else:
+        _, cst = ds.render_tiles(cam, tw, th, rank, world)
+    ds.set_counters(False)
+    rays_rank = int(cst["rays"])
+    sample_f = cpu_sample_factor(hs.desc, cam)
+    ref_counts = o_rgb = o_hits = None
+    ocam = cam if sample_f == 1 else reduced_camera(cam, sample_f)
+    if mode == "frames" and (rank == 0 or world == 1):
+        R.note(f"reference work counts on the host (sample factor {sample_f})")
+        ref_counts, o_rgb, o_hits, _ = oracle_frame(hs.desc, ocam, R.host_threads, want_hits=True)
+    counters_agree = None
+    if ref_counts is not None and sample_f > 1:
+        # bounded sample: the same view at 1/f of the resolution in both directions, counts scaled
+        # to the full frame by the device's own ray count
+        scale = rays_rank / max(ref_counts["rays"], 1)
+        ref_scaled = {k: int(round(v * scale)) for k, v in ref_counts.items()}
+        ref_b = reference_bytes(ref_scaled)
+        alg_source = (f"reference algorithm's work counts (CPU restatement on the same view at 1/{sample_f} resolution, "
+                      "scaled to the frame's ray count) x reference record sizes")
+    elif ref_counts is not None:
+        # (world-box tests are not compared: the device's TLAS rejects most instances before
+        # their boxes are tested, the reference tests every instance's box, utils.cpp:756-766)
+        counters_agree = ref_counts["rays"] == cst["rays"] and ref_counts["tri_tests"] == cst["tri_tests"]
+        ref_scaled = ref_counts
+        ref_b = reference_bytes(ref_counts)
+        alg_source = "reference algorithm's work counts (CPU restatement, untimed pass) x reference record sizes"
+    else:
+        ref_scaled, ref_b, alg_source = None, None, None
+    dev_b = device_bytes(cst)
+    flops = frame_flops(cst, ref_scaled)
+
+    # ---- parity of this very frame (rank 0): device (default mode) against the checker -------
+    parity = None
+    if o_rgb is not None:
+        d_rgb, d_hits, _ = ds.render(ocam, want_hits=True)
+        parity = {"view": f"{ocam.width}x{ocam.height}" + ("" if sample_f == 1 else f" (the frame's view at 1/{sample_f})"),
+                  "vs_oracle": {**image_delta(d_rgb, o_rgb), "hit_mismatches": hit_mismatches(d_hits, o_hits),
+                                "pixels": int(ocam.width * ocam.height)}}
+        parity_rgb = d_rgb.copy()
+
+    # the caller-owned image buffer of the C-ABI: page-locked and reused from frame to frame
+    frame = R.pinned(cam.height * cam.width * 3).reshape(cam.height, cam.width, 3)
+    if args.consistent:
+        ds.set_consistent(True)
+    if mode == "frames":
+        def step(i):
+            return ds.render(cam, out=frame)[2]
+    else:
+        gatherer = D.TileGatherer(cam.width, cam.height, tw, th, rank, world, device=R.red_dev,
+                                  unpack=rt.unpack_tiles, frame=frame)
+        last = {}
+
+        def render_tiles(first, stride, out):
+            _, st = ds.render_tiles(cam, tw, th, first, stride, out_ptr=out.data_ptr(), out_is_device=out.is_cuda)
+            last["st"] = st
+
+        def step(i):
+            gatherer.run(render_tiles)
+            return last["st"]
+    R.note("timed steps")
+    elapsed, stats = timed(R, step, steps, warmup)
+    kernel_ms = sum(s["kernel_ms"] for s in stats)
+    trace_ms = sum(s["trace_ms"] for s in stats)
+    trace_launches = sum(s["trace_launches"] for s in stats)
+    rays_step, = R.reduce([rays_rank])
+    out = None
+    if rank == 0:
+        ms_per_step = elapsed / steps * 1e3
+        # Dominant kernel: k_trace, the closest-hit traversal, launched once per ray generation (two
+        # variants per generation, one of which returns at once).  Every generation's launches are
+        # bracketed by HIP events on the library's own stream (rtx_stats.trace_ms / trace_launches).
+        launches_per_frame = trace_launches / steps
+        avg_launch_ms = trace_ms / max(trace_launches, 1)
+        # algorithmic bytes: the reference's algorithm in its record sizes -- unless the device's own
+        # records for the same frame are fewer bytes (it replaces the reference's linear instance loop
+        # by a TLAS): then those, so that the fraction never counts bytes nobody has to move
+        basis = "reference" if (ref_b is not None and ref_b <= dev_b) else "device"
+        alg_b = ref_b if basis == "reference" else dev_b
+        bytes_per_launch = alg_b / max(launches_per_frame, 1)
+        t_launch = avg_launch_ms * 1e-3
+        achieved = bytes_per_launch / t_launch / 1e9 if t_launch > 0 else 0.0
+        t_trace_frame = trace_ms / steps * 1e-3
+        traffic = None
+        tfile = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tfile):
+            try:
+                with open(tfile) as f:
+                    tj = json.load(f)
+                if tj.get("workload") == name:
+                    traffic = tj.get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        tflops = flops / t_trace_frame / 1e12 if t_trace_frame > 0 else 0.0
+        roofline = {
+            "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+            "kernel": "k_trace (closest-hit traversal; all variants of a generation)",
+            "launches_per_frame": launches_per_frame, "avg_launch_ms": avg_launch_ms,
+            "trace_ms_per_frame": trace_ms / steps, "all_kernels_ms_per_frame": kernel_ms / steps,
+            "algorithmic_basis": basis,
+            "algorithmic_bytes_per_launch": bytes_per_launch, "algorithmic_bytes_per_frame": alg_b,
+            "algorithmic_bytes_per_ray": alg_b / max(rays_rank, 1),
+            "reference_bytes_per_frame": ref_b, "reference_bytes_source": alg_source,
+            "device_bytes_per_frame": dev_b,
+            "device_bytes_source": "device counters (counters on) x device record sizes: 256 B per BLAS/TLAS record visit, "
+                                   "128 B per triangle test, world-box test and object-space transform, 96 B per queued ray, "
+                                   "128 B per hit record",
+            "l2": {"achieved": dev_b / t_trace_frame / 1e9 if t_trace_frame > 0 else 0.0, "peak": L2_PEAK_GBS,
+                   "unit": "GB/s", "frac": (dev_b / t_trace_frame / 1e9 / L2_PEAK_GBS) if t_trace_frame > 0 else 0.0,
+                   "note": "device record bytes of the frame / trace time: the rate at which records leave the caches "
+                           "(most of them L2 or Infinity Cache hits), against the aggregate L2 bandwidth"},
+            "valu": {"flops_per_frame": flops, "achieved": tflops, "unit": "TFLOP/s",
+                     "fp64_peak": FP64_VALU_PEAK_TF, "frac_fp64": tflops / FP64_VALU_PEAK_TF,
+                     "fp32_peak": FP32_VALU_PEAK_TF, "frac_fp32": tflops / FP32_VALU_PEAK_TF,
+                     "model": "FP64 operations of the device's own arithmetic: 100 per four-wide record visit (4 slab tests "
+                              "of 25), triangle tests by the stage they reach (19 / +10 / +20 / +17), 25 per world-box "
+                              "test, 53 per ray taken to object space, 150 per shaded hit, 60 per shadow ray; counts from "
+                              "the device counters and the CPU restatement's stage counters"},
+            "counters_agree": counters_agree,
+            "reference_work_counts": ref_scaled,
+            "device_record_visits": int(cst["node_visits"]), "tri_tests": int(cst["tri_tests"]),
+            "device_world_box_tests": int(cst["world_box_tests"]),
+            "device_object_space_traversals": int(cst["object_space_traversals"]),
+            "device_tlas_node_visits": int(cst["tlas_node_visits"]),
+            "lanes_at_nodes_per_wave_step": cst["wave_inner_lanes"] / max(cst["wave_inner_steps"], 1),
+            "lanes_at_leaves_per_wave_step": cst["wave_leaf_lanes"] / max(cst["wave_leaf_steps"], 1),
+            "occupancy_waves_per_simd": 2,
+            "pmc": pmc_summary(name),
+        }
+        out = {
+            "metric": "Mrays/s (ms/frame in ms_per_step)", "value": rays_step * steps / elapsed / 1e6, "unit": "Mrays/s",
+            "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": "weak" if mode == "frames" else "strong",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": name, "description": descr, "mode": mode,
+                       "sharding": ("whole frames: rank r renders orbit frame r of the scene every step, no collective"
+                                    if mode == "frames" else
+                                    f"interleaved {tw}x{th} tiles of one frame, one gather to rank 0 per frame"),
+                       "resolution": [cam.width, cam.height], "rays_per_step": rays_step,
+                       "rays_per_pixel": rays_rank / (cam.width * cam.height) if mode == "frames" else None,
+                       "frames_per_step": world if mode == "frames" else 1,
+                       "host_load_s": t_load, "scene_upload_s": t_upload,
+                       "image_buffer": "host, page-locked, reused (download inside the timed step)",
+                       "traversal": ("consistent mode: not the reference's results where instances are scaled; rays and "
+                                     "algorithmic bytes are those of the same frame in the default mode")
+                                    if args.consistent else "reference-exact (default)"},
+            "roofline": roofline,
+        }
+        if with_cpu:
+            R.note("reference CPU renderer")
+            cb, ref_img = cpu_reference_baseline(path, rays_rank, sample_f)
+            if cb is not None:
+                out["cpu_baseline"] = cb
+                out["config"]["speedup_vs_cpu_reference_ms_per_frame"] = cb["ms_per_frame"] / ms_per_step
+                if parity is not None and ref_img is not None and ref_img.shape == parity_rgb.shape:
+                    parity["vs_reference_ppm"] = image_delta(parity_rgb, ref_img)
+        if parity is not None:
+            out["parity"] = parity
+    ds.close()
+    hs.close()
+    return out
+
+
+def measure_sequence(R: Rank, args, name, steps, warmup, whole):
+    """camera_around_david: rank r renders frames r, r + N, ... of the 360-frame sequence through
+    the animation pipeline (geometry loaded and uploaded once per rank; per frame the scene
+    file is re-read for camera and lights only).  whole: every frame of the sequence once
+    (steps is ignored); otherwise `steps` frames per rank after `warmup` earlier ones."""
+    import raytracer_amd as rt
+    from raytracer_amd import distributed as D
+    world, rank = R.world, R.rank
+    n_seq = SEQUENCE_FRAMES
+    if whole:
+        mine = D.shard_frames(n_seq, rank, world)
+        warm = mine[:1]
+    else:
+        mine = [(rank + i * world) % n_seq for i in range(steps)]
+        warm = [(rank + (i - warmup) * world) % n_seq for i in range(warmup)]
+    needed = sorted(set(range(n_seq)) if whole else set(f for r in range(world) for i in range(-warmup, steps)
+                                                        for f in [(r + i * world) % n_seq]))
+    files = dict(zip(needed, R.workload(name, needed)))
+    descr = files[needed[0]][1]
+    R.note(f"sequence {name}: loading the geometry once per rank")
+    t0 = time.time()
+    hs = rt.HostScene(files[mine[0]][0])
+    ds = rt.DeviceScene(hs.desc, R.local_rank)
+    t_setup = time.time() - t0
+    cam, _ = hs.camera(0)
+    frame = R.pinned(cam.height * cam.width * 3).reshape(cam.height, cam.width, 3)
+
+    def render(f, counters=False):
+        if not hs.load_next(files[f][0]):
+            raise SystemExit(f"frame {f}: the geometry was not kept")
+        ds.update_lights(hs.lights())
+        c, _ = hs.camera(0)
+        return ds.render(c, out=frame)[2]
+
+    R.note("sequence: device counting pass")
+    ds.set_counters(True)
+    rays_mine = sum(int(render(f)["rays"]) for f in mine)
+    ds.set_counters(False)
+    R.note("sequence: timed frames")
+    for f in warm:
+        render(f)
+    R.barrier()
+    t0 = time.perf_counter()
+    stats = [render(f) for f in mine]
+    R.barrier()
+    elapsed = R.reduce([time.perf_counter() - t0], "max")[0]
+    rays_all, frames_all = R.reduce([rays_mine, len(mine)])
+    out = None
+    if rank == 0:
+        per_rank = max(len(D.shard_frames(n_seq, r, world)) for r in range(world)) if whole else steps
+        out = {"workload": name, "description": descr,
+               "sharding": "whole frames: frame f of the sequence on rank f mod N, no collective; geometry parsed, built "
+                           "and uploaded once per rank, camera and lights re-read per frame",
+               "frames": int(frames_all), "frames_per_rank": per_rank, "wall_s": elapsed,
+               "frames_per_s": frames_all / elapsed, "ms_per_frame_per_gpu": elapsed / per_rank * 1e3,
+               "Mrays_per_s": rays_all / elapsed / 1e6, "rays": int(rays_all), "resolution": [cam.width, cam.height],
+               "setup_s_per_rank": t_setup, "kernel_ms_per_frame": sum(s["kernel_ms"] for s in stats) / max(len(stats), 1),
+               "trace_ms_per_frame": sum(s["trace_ms"] for s in stats) / max(len(stats), 1),
+               "trace_launches_per_frame": sum(s["trace_launches"] for s in stats) / max(len(stats), 1),
+               "n_gpus": world}
+    ds.close()
+    hs.close()
+    return out
+
+
+def run_rank(args) -> int:
+    R = Rank(args)
+    world = R.world
+    extras = (not args.no_extras and args.workload == "dragon_metal" and args.mode == "frames" and not args.consistent)
+    if is_sequence(args.workload):
+        seq = measure_sequence(R, args, args.workload, args.steps, args.warmup, whole=False)
+        out = None
+        if R.rank == 0:
+            out = {"metric": "Mrays/s (ms/frame in ms_per_step)", "value": seq["Mrays_per_s"], "unit": "Mrays/s",
+                   "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": seq["wall_s"] / args.steps * 1e3,
+                   "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+                   "config": {"workload": args.workload, "description": seq["description"], "mode": "frames",
+                              "sharding": seq["sharding"], "frames_per_step": world, "frames_per_s": seq["frames_per_s"],
+                              "rays_per_step": seq["rays"] / args.steps, "resolution": seq["resolution"]},
+                   "sequence": seq}
+    else:
+        out = measure_static(R, args, args.workload, args.mode, args.steps, args.warmup,
+                             with_cpu=(world == 1 and not args.no_cpu_baseline))
+    if extras:
+        # the two other shardings of the path, measured after the main one and reported beside it
+        seq = measure_sequence(R, args, "camera_around_david", 0, 0, whole=True)
+        tiles = measure_static(R, args, "grass_desert", "tiles", 5, 1, with_cpu=False)
+        if R.rank == 0:
+            out["sequence"] = seq
+            out["tiled_frame"] = {k: tiles[k] for k in ("value", "unit", "ms_per_step", "n_gpus", "steps", "scaling")}
+            out["tiled_frame"].update({"workload": "grass_desert", "sharding": tiles["config"]["sharding"],
+                                       "resolution": tiles["config"]["resolution"],
+                                       "rays_per_frame": tiles["config"]["rays_per_step"],
+                                       "trace_ms_per_frame_rank0": tiles["roofline"]["trace_ms_per_frame"],
+                                       "l2": tiles["roofline"]["l2"],
+                                       "device_bytes_per_frame_rank0": tiles["roofline"]["device_bytes_per_frame"]})
+    if R.rank == 0:
+        print(json.dumps(out), flush=True)
+    R.close()
+    return 0
+
+
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -224,230 +799,29 @@ def main():
     ap.add_argument("--mode", choices=["frames", "tiles"], default="frames")
     ap.add_argument("--tile", default="64x8")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the sequence and tiled-frame measurements that follow the default workload")
     ap.add_argument("--consistent", action="store_true",
                     help="time the library's consistent mode (NOT the reference's results for scaled instances; "
                          "never the headline number).  Rays and algorithmic bytes stay those of the same frame in "
                          "the default, reference-exact mode")
-    args = ap.parse_args()
+    ap.add_argument("--selftest-ranks", action="store_true",
+                    help="check the rank launch path only: rendezvous over gloo, no GPU work")
+    ap.add_argument("--selftest-fail-rank", type=int, default=-1, help=argparse.SUPPRESS)
+    return ap.parse_args(argv)
 
-    import torch
-    import raytracer_amd as rt
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: there is no CPU path behind the C-ABI")
-    # Rehearsal on a one-GPU box (RTX_BENCH_REHEARSAL=1): every rank uses device 0 and the
-    # collectives run over gloo on host tensors; everything else is the multi-GPU code path.
-    rehearsal = os.environ.get("RTX_BENCH_REHEARSAL") == "1"
-    if rehearsal:
-        local_rank = 0
-    torch.cuda.set_device(local_rank)
-    red_dev = "cpu" if rehearsal else "cuda"
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if rehearsal:
-            dist.init_process_group("gloo")
-        else:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-
-    def barrier():
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    d = scene_cache_dir()
-    if rank == 0:
-        path, descr = make_workload(args.workload, d)
-    barrier()
-    path, descr = make_workload(args.workload, d)
-
-    def note(msg):
-        if rank == 0:
-            print(f"[bench] {msg}", file=sys.stderr, flush=True)
-
-    note(f"workload {args.workload}: loading scene")
-    t0 = time.time()
-    hs = rt.HostScene(path)
-    t_load = time.time() - t0
-    t0 = time.time()
-    ds = rt.DeviceScene(hs.desc, local_rank)
-    t_upload = time.time() - t0
-    cam0, _ = hs.camera(0)
-    tw, th = (int(x) for x in args.tile.split("x"))
-
-    if args.mode == "frames":
-        cam = orbit_camera(cam0, 360.0 * rank / max(world, 1) if world > 1 else 0.0)
-    else:
-        cam = cam0
-
-    # ---- untimed counting pass: rays and traversal work of this rank's step ----------------
-    note("device counting pass")
-    ds.set_counters(True)
-    if args.mode == "frames":
-        _, _, cst = ds.render(cam)
-    else:
-        _, cst = ds.render_tiles(cam, tw, th, rank, world)
-    ds.set_counters(False)
-    rays_rank = int(cst["rays"])
-    host_threads = max(1, min(16, os.cpu_count() or 1) // max(world, 1)) if world > 1 else min(16, os.cpu_count() or 1)
-    ref_counts, oracle_ms = (None, None)
-    sample_f = cpu_sample_factor(hs.desc, cam)
-    note(f"reference work counts on the host (sample factor {sample_f})")
-    if args.mode == "frames":
-        ref_counts, oracle_ms = reference_work_counts(hs.desc, cam if sample_f == 1 else reduced_camera(cam, sample_f),
-                                                      host_threads)
-    if ref_counts is not None and sample_f > 1:
-        # bounded sample: the same view at 1/f of the resolution in both directions, counts scaled
-        # to the full frame by the device's own ray count
-        scale = rays_rank / max(ref_counts["rays"], 1)
-        ref_counts = {k: int(round(v * scale)) for k, v in ref_counts.items()}
-        counters_agree = None
-        alg_bytes_rank = algorithmic_bytes(ref_counts)
-        alg_source = (f"reference algorithm's work counts (CPU restatement on the same view at 1/{sample_f} resolution, "
-                      "scaled to the frame's ray count) x reference record sizes")
-    elif ref_counts is not None:
-        # (world-box tests are not compared: the device's TLAS rejects most instances before
-        # their boxes are tested, the reference tests every instance's box, utils.cpp:756-766)
-        counters_agree = ref_counts["rays"] == cst["rays"] and ref_counts["tri_tests"] == cst["tri_tests"]
-        alg_bytes_rank = algorithmic_bytes(ref_counts)
-        alg_source = "reference algorithm's work counts (CPU restatement, untimed pass) x reference record sizes"
-    else:
-        # tiles mode / checker not built: the device's counters, a collapsed-node visit priced as the
-        # three binary nodes it stands for at most
-        counters_agree = None
-        alg_bytes_rank = algorithmic_bytes({"node_pops": 3 * cst["node_visits"], "tri_tests": cst["tri_tests"],
-                                            "world_box_tests": cst["world_box_tests"],
-                                            "ray_transforms": cst["object_space_traversals"],
-                                            "transformed_hits": 0, "rays": cst["rays"]})
-        alg_source = "device counters (estimate)"
-
-    # the caller-owned image buffer of the C-ABI: page-locked and reused from frame to frame
-    frame = torch.empty((cam.height, cam.width, 3), dtype=torch.uint8).pin_memory().numpy()
-    gather_buf = None
-    my_bytes = ds.tile_bytes(cam, tw, th, rank, world) if args.mode == "tiles" else 0
-    if args.mode == "tiles":
-        sizes = [ds.tile_bytes(cam, tw, th, r, world) for r in range(world)]
-        pad = max(sizes)
-        my_dev = torch.empty(pad, dtype=torch.uint8, device="cuda")
-        if rank == 0 and world > 1:
-            gather_buf = [torch.empty(pad, dtype=torch.uint8, device=red_dev) for _ in range(world)]
-
-    def step():
-        if args.mode == "frames":
-            _, _, st = ds.render(cam, out=frame)
-            return st
-        _, st = ds.render_tiles(cam, tw, th, rank, world, out_ptr=my_dev.data_ptr(), out_is_device=True)
-        if world > 1:
-            dist.gather(my_dev.cpu() if rehearsal else my_dev, gather_buf, dst=0)
-        if rank == 0:
-            parts = gather_buf if world > 1 else [my_dev]
-            for r, t in enumerate(parts):
-                rt.unpack_tiles(t[:sizes[r]].cpu().numpy(), cam.width, cam.height, tw, th, r, world, frame)
-        return st
-
-    if args.consistent:
-        ds.set_consistent(True)
-    note("timed steps")
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    t0 = time.perf_counter()
-    kernel_ms = 0.0
-    trace_ms = 0.0
-    trace_launches = 0
-    for _ in range(args.steps):
-        st = step()
-        kernel_ms += st["kernel_ms"]
-        trace_ms += st["trace_ms"]
-        trace_launches += st["trace_launches"]
-    barrier()
-    elapsed = time.perf_counter() - t0
-
-    el = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
-    tot = torch.tensor([float(rays_rank), float(alg_bytes_rank)], dtype=torch.float64, device=red_dev)
-    if dist is not None:
-        dist.all_reduce(el, op=dist.ReduceOp.MAX)
-        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
-    elapsed = float(el.item())
-    rays_step = float(tot[0].item())
-
-    if rank == 0:
-        ms_per_step = elapsed / args.steps * 1e3
-        mrays = rays_step * args.steps / elapsed / 1e6
-        # Dominant kernel: k_trace, one launch per ray generation.  Its launches are bracketed by HIP
-        # events on the library's own stream (rtx_stats.trace_ms / trace_launches).  A launch
-        # processes, on average, 1/launches_per_frame of the frame's algorithmic bytes.
-        launches_per_frame = trace_launches / args.steps
-        avg_launch_ms = trace_ms / max(trace_launches, 1)
-        bytes_per_launch = alg_bytes_rank / max(launches_per_frame, 1)
-        achieved = bytes_per_launch / (avg_launch_ms * 1e-3) / 1e9 if avg_launch_ms > 0 else 0.0
-        k_ms_frame = kernel_ms / args.steps                    # every kernel of rank 0's frame
-        traffic = None
-        tfile = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tfile):
-            try:
-                with open(tfile) as f:
-                    tj = json.load(f)
-                if tj.get("workload") == args.workload:
-                    traffic = tj.get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
-        out = {
-            "metric": "Mrays/s (ms/frame in ms_per_step)", "value": mrays, "unit": "Mrays/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
-            "higher_is_better": True, "scaling": "weak" if args.mode == "frames" else "strong",
-            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": args.workload, "description": descr, "mode": args.mode,
-                       "resolution": [cam.width, cam.height], "rays_per_step": rays_step,
-                       "rays_per_pixel": rays_rank / (cam.width * cam.height) if args.mode == "frames" else None,
-                       "frames_per_step": world if args.mode == "frames" else 1,
-                       "host_load_s": t_load, "scene_upload_s": t_upload,
-                       "image_buffer": "host, page-locked, reused (download inside the timed step)",
-                       "traversal": ("consistent mode: not the reference's results where instances are scaled; rays and "
-                                     "algorithmic bytes are those of the same frame in the default mode")
-                                    if args.consistent else "reference-exact (default)"},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "k_trace", "launches_per_frame": launches_per_frame,
-                         "avg_launch_ms": avg_launch_ms, "trace_ms_per_frame": trace_ms / args.steps,
-                         "all_kernels_ms_per_frame": k_ms_frame,
-                         "algorithmic_bytes_per_launch": bytes_per_launch,
-                         "algorithmic_bytes_per_frame": alg_bytes_rank,
-                         "algorithmic_bytes_per_ray": alg_bytes_rank / max(rays_rank, 1),
-                         "algorithmic_source": alg_source, "counters_agree": counters_agree,
-                         "note": ("algorithmic bytes are those of the reference's algorithm (its work counts x its record "
-                                  "sizes); the device may undercut them with result-identical shortcuts (TLAS instead of the "
-                                  "linear instance loop, early retirement of occluded shadow rays, caches), so on workloads "
-                                  "where the reference re-reads a small working set per ray frac can exceed 1"),
-                         "reference_work_counts": ref_counts,
-                         "device_record_visits": int(cst["node_visits"]), "tri_tests": int(cst["tri_tests"]),
-                         "device_world_box_tests": int(cst["world_box_tests"]),
-                         "device_object_space_traversals": int(cst["object_space_traversals"]),
-                         "device_tlas_node_visits": int(cst["tlas_node_visits"]),
-                         "lanes_at_nodes_per_wave_step": cst["wave_inner_lanes"] / max(cst["wave_inner_steps"], 1),
-                         "lanes_at_leaves_per_wave_step": cst["wave_leaf_lanes"] / max(cst["wave_leaf_steps"], 1),
-                         "wave_steps_with_node_lanes": int(cst["wave_inner_steps"]),
-                         "wave_steps_with_leaf_lanes": int(cst["wave_leaf_steps"])},
-        }
-        if world == 1 and not args.no_cpu_baseline:
-            note("reference CPU renderer")
-            cb = cpu_reference_baseline(path, rays_rank, sample_f)
-            if cb is not None:
-                out["cpu_baseline"] = cb
-                out["config"]["speedup_vs_cpu_reference_ms_per_frame"] = cb["ms_per_frame"] / ms_per_step
-        print(json.dumps(out), flush=True)
-    ds.close()
-    hs.close()
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+def main(argv=None) -> int:
+    argv = sys.argv[1:] if argv is None else list(argv)
+    args = parse_args(argv)
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be at least 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return launch_ranks(args.gpus, argv)
+    if args.selftest_ranks:
+        return selftest_rank(args)
+    return run_rank(args)
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -6,7 +6,7 @@
  * It exists only to check the HIP path: tests/, __graft_entry__.smoke() and the
  * cpu_baseline leg of bench.py may load it; nothing the product ships links it.
  *
- * Parity is PINNED: tests/test_oracle_vs_reference.py compares this file's images and
+ * Parity is PINNED: tests/test_oracle.py and tests/test_fuzz_cpu.py compare this file's images and
  * hit records byte-for-byte with the compiled reference (oracle/_ref, built from the
  * reference's own sources) on every unit scene, and tests/golden/ holds the reference's
  * outputs for the same scenes so that the check also runs where the reference is absent.
@@ -36,6 +36,9 @@ typedef struct {
     uint64_t ray_transforms;   /* rays taken to object space (utils.cpp:481-489)          */
     uint64_t transformed_hits; /* accepted back-transformed hits (utils.cpp:572-659)      */
     uint64_t shades;           /* computeShading calls with a material                    */
+    /* how far the triangle tests got (utils.cpp:342, 352, 359): beyond the determinant guard and
+     * culling, beyond the beta test, beyond the gamma test -- the stages differ in arithmetic */
+    uint64_t tri_past_det, tri_past_beta, tri_past_gamma;
 } rt_oracle_counters;
 
 /* Intersection (scene.h:248-264) + the producing object for attribution. */
@@ -167,14 +170,17 @@ static int tri_hit(const ctx_t* cx, const ray_t* ray, const int32_t* face, doubl
                    e1z * (e2x * dy - e2y * dx));
     if (fabs(det) < 1e-15) return 0;
     const double invDet = 1.0 / det;
+    cx->c->tri_past_det++;
     double detB = -(rx * (e2y * dz - e2z * dy) - ry * (e2x * dz - e2z * dx) +
                     rz * (e2x * dy - e2y * dx));
     double beta = detB * invDet;
     if (beta < 0.0 || beta > 1.0) return 0;
+    cx->c->tri_past_beta++;
     double detG = -(e1x * (ry * dz - rz * dy) - e1y * (rx * dz - rz * dx) +
                     e1z * (rx * dy - ry * dx));
     double gamma = detG * invDet;
     if (gamma < 0.0 || gamma > 1.0 || beta + gamma > 1.0) return 0;
+    cx->c->tri_past_gamma++;
     double detT = e1x * (e2y * rz - e2z * ry) - e1y * (e2x * rz - e2z * rx) +
                   e1z * (e2x * ry - e2y * rx);
     double t = detT * invDet;

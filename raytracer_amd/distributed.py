@@ -45,30 +45,64 @@ def unpack_tiles_numpy(packed, width, height, tile_w, tile_h, first, stride, fra
     return frame
 
 
+class TileGatherer:
+    """The tile path of one frame size, with its buffers allocated once: every rank renders its
+    interleaved tiles into one packed buffer, rank 0 receives all buffers with ONE gather and
+    scatters the tiles into the frame.
+
+    device: where the packed buffers live -- "cuda" for RCCL (the render call writes device
+    memory and the gather moves it over xGMI), "cpu" for gloo.  unpack: rtx_unpack_tiles or its
+    numpy twin.  frame: optional caller-owned uint8 [height][width][3] array for rank 0's result.
+    """
+
+    def __init__(self, width, height, tile_w, tile_h, rank, world, group=None, device="cpu",
+                 unpack=unpack_tiles_numpy, frame=None):
+        import torch
+        self.geom = (width, height, tile_w, tile_h)
+        self.rank, self.world, self.group, self.unpack = rank, world, group, unpack
+        self.sizes = [packed_tile_bytes(width, height, tile_w, tile_h, r, world) for r in range(world)]
+        pad = max(max(self.sizes), 1)
+        self.mine = torch.zeros(pad, dtype=torch.uint8, device=device)
+        self.parts = None
+        self.stage = None
+        if rank == 0:
+            self.parts = [self.mine] if world == 1 else [torch.empty(pad, dtype=torch.uint8, device=device) for _ in range(world)]
+            if self.mine.is_cuda:                       # page-locked landing area for the device buffers
+                self.stage = torch.empty((world, pad), dtype=torch.uint8).pin_memory()
+            self.frame = frame if frame is not None else np.zeros((height, width, 3), dtype=np.uint8)
+
+    def run(self, render_tiles):
+        """render_tiles(first, stride, out) must fill the 1-D uint8 tensor `out` with the packed
+        tiles first, first+stride, ...  Returns the frame on rank 0 and None elsewhere."""
+        import torch
+        import torch.distributed as dist
+        width, height, tile_w, tile_h = self.geom
+        if self.sizes[self.rank]:
+            render_tiles(self.rank, self.world, self.mine[:self.sizes[self.rank]])
+        if self.world > 1:
+            dist.gather(self.mine, self.parts, dst=0, group=self.group)
+        if self.rank != 0:
+            return None
+        if self.stage is not None:
+            for r, t in enumerate(self.parts):
+                if self.sizes[r]:
+                    self.stage[r, :self.sizes[r]].copy_(t[:self.sizes[r]], non_blocking=True)
+            torch.cuda.synchronize()
+            host = [self.stage[r] for r in range(self.world)]
+        else:
+            host = self.parts
+        for r, t in enumerate(host):
+            if self.sizes[r]:
+                self.unpack(t[:self.sizes[r]].numpy(), width, height, tile_w, tile_h, r, self.world, self.frame)
+        return self.frame
+
+
 def gather_tiled_frame(render_tiles, width, height, tile_w, tile_h, rank, world, group=None,
                        device="cpu", unpack=unpack_tiles_numpy):
-    """Render this rank's tiles and assemble the frame on rank 0.
+    """Render this rank's tiles and assemble the frame on rank 0 (one-shot form of TileGatherer).
 
     render_tiles(first, stride, out) must fill the 1-D uint8 torch tensor `out` (on
     `device`) with the packed tiles first, first+stride, ...  Returns the uint8
     [height][width][3] frame on rank 0 and None elsewhere.
     """
-    import torch
-    import torch.distributed as dist
-    sizes = [packed_tile_bytes(width, height, tile_w, tile_h, r, world) for r in range(world)]
-    pad = max(max(sizes), 1)
-    mine = torch.zeros(pad, dtype=torch.uint8, device=device)
-    if sizes[rank]:
-        render_tiles(rank, world, mine[:sizes[rank]])
-    parts = [mine]
-    if world > 1:
-        bufs = [torch.empty(pad, dtype=torch.uint8, device=device) for _ in range(world)] if rank == 0 else None
-        dist.gather(mine, bufs, dst=0, group=group)
-        parts = bufs
-    if rank != 0:
-        return None
-    frame = np.zeros((height, width, 3), dtype=np.uint8)
-    for r, t in enumerate(parts):
-        if sizes[r]:
-            unpack(t[:sizes[r]].cpu().numpy(), width, height, tile_w, tile_h, r, world, frame)
-    return frame
+    return TileGatherer(width, height, tile_w, tile_h, rank, world, group, device, unpack).run(render_tiles)

@@ -22,7 +22,8 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 class OracleCounters(C.Structure):
     _fields_ = [(k, C.c_uint64) for k in
                 ("rays", "primary_rays", "shadow_rays", "secondary_rays", "node_pops", "tri_tests",
-                 "world_box_tests", "ray_transforms", "transformed_hits", "shades")]
+                 "world_box_tests", "ray_transforms", "transformed_hits", "shades",
+                 "tri_past_det", "tri_past_beta", "tri_past_gamma")]
 
     def as_dict(self):
         return {k: int(getattr(self, k)) for k, _ in self._fields_}
