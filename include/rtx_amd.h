@@ -140,7 +140,9 @@ typedef struct rtx_hit_id { int32_t kind, container, face, src; double distance;
 
 /* Work counters of one rtx_render call.  A "ray" is one closest-hit query the reference
  * semantics require (one intersect() call, utils.cpp:671), excluding the calls whose result
- * computePixelColor discards because depth > maxRecursionDepth (utils.cpp:1047). */
+ * computePixelColor discards because depth > maxRecursionDepth (utils.cpp:1047).  The four ray
+ * counts, the times and generations / queue_overflows are always filled; the traversal counts
+ * (node_visits ... wave_leaf_lanes) only with rtx_scene_set_counters on. */
 typedef struct rtx_stats {
     uint64_t rays, primary_rays, shadow_rays, secondary_rays;
     uint64_t node_visits;      /* BLAS record visits (one record = two binary BVH levels) */

@@ -1016,8 +1016,25 @@ int render_frame(rtx_scene* sc, const rtx_camera* cam, int32_t tw, int32_t th, i
                     (double)ctr.section[k] / std::max(1ull, ctr.section[4 + k]));
     }
     if (stats) {
-        stats->rays = ctr.rays; stats->primary_rays = ctr.primary; stats->shadow_rays = ctr.shadow;
-        stats->secondary_rays = ctr.secondary; stats->node_visits = ctr.node_visits; stats->tri_tests = ctr.tri_tests;
+        if (sc->counters_on) {
+            stats->rays = ctr.rays; stats->primary_rays = ctr.primary; stats->shadow_rays = ctr.shadow;
+            stats->secondary_rays = ctr.secondary;
+        } else {
+            // The ray counts need no device counters: one primary ray per pixel of the selected
+            // tiles, and every later ray passed through a queue whose fill levels came back with
+            // the control blocks.
+            uint64_t primary = 0, radiance = 0, shadow = 0;
+            for (int k = 0; k < g.n_sel; k++) {
+                const int tile = first + k * stride;
+                const int x0 = (tile % g.tiles_x) * tw, y0 = (tile / g.tiles_x) * th;
+                primary += (uint64_t)std::max(0, std::min(tw, cam->width - x0)) * (uint64_t)std::max(0, std::min(th, cam->height - y0));
+            }
+            for (int k = 1; k <= G; k++)
+                for (const SubCount& sub : sc->h_ctrl[k].sub) { radiance += sub.counts & 0xFFFFFFFFull; shadow += sub.counts >> 32; }
+            stats->primary_rays = primary; stats->secondary_rays = radiance; stats->shadow_rays = shadow;
+            stats->rays = primary + radiance + shadow;
+        }
+        stats->node_visits = ctr.node_visits; stats->tri_tests = ctr.tri_tests;
         stats->world_box_tests = ctr.world_box_tests; stats->object_space_traversals = ctr.object_traversals;
         stats->tlas_node_visits = ctr.tlas_visits;
         stats->wave_inner_steps = ctr.inner_steps; stats->wave_inner_lanes = ctr.inner_lanes;

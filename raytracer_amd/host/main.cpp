@@ -2,7 +2,8 @@
 // that renders on the MI355X core instead of the CPU loops.
 //
 //   raytracer_amd <scene.json> [more.json ...] [-b [0|1]] [-m [0|1]] [-c [0|1]]
-//                 [--device D] [--shard R/N] [--out DIR] [--png] [--quiet] [--gpu-build] [--consistent]
+//                 [--device D | --gpus N | --devices a,b,..] [--tile WxH] [--resolution WxH]
+//                 [--shard R/N] [--out DIR] [--png] [--quiet] [--gpu-build] [--consistent]
 //
 // -b  BVH on/off (default on; `-b` alone = on).  Off ships meshes without a BVH; the device
 //     then tests every face of a mesh in face order, like the reference's brute-force loop.
@@ -14,6 +15,14 @@
 //     pictures where a scene has scaled instances.
 // --shard R/N  render only scene files i with i % N == R (whole-frame sharding of an
 //     animation across N processes, one per GPU; no communication needed).
+// --gpus N / --devices a,b,..  split every frame over several GPUs of this process: the scene is
+//     uploaded to each, device k renders the interleaved tiles k, k + n, ... (--tile WxH, default
+//     64x8) on a host thread of its own, and the packed tiles are assembled into the frame here
+//     (the reference splits a frame into row bands over its threads, raytracer.cpp:107-126;
+//     interleaved tiles balance scenes whose geometry sits in one strip).  A device may be named
+//     more than once (two tile streams on one GPU).
+// --resolution WxH  render every camera at this resolution instead of the scene file's
+//     ImageResolution (same view: keep the aspect ratio).
 //
 // For every camera it writes <out>/<ImageName stem>.ppm (ASCII P3, byte-identical layout to
 // scene.cpp:675-697), optionally a .png, and <stem>_results.json with the reference's keys
@@ -24,6 +33,7 @@
 // predecessor's keeps the loaded scene and its device copy and only takes over cameras and
 // lights (rtx_host_load_next + rtx_scene_update_lights), and pictures are encoded and
 // written by a second thread while the next frame renders.
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
@@ -114,6 +124,8 @@ int main(int argc, char** argv) {
     std::vector<std::string> scenes;
     bool use_bvh = true, cull = false, multithreaded = true, png = false, quiet = false, gpu_build = false, consistent = false;
     int device = 0, shard_r = 0, shard_n = 1;
+    std::vector<int> devices;
+    int tile_w = 64, tile_h = 8, res_w = 0, res_h = 0;
     std::string out_dir = "../my_outputs_hw2/";            // raytracer.cpp:13
     auto opt01 = [&](int& i, bool bare_value, bool& target) {
         if (i + 1 < argc && (!strcmp(argv[i + 1], "0") || !strcmp(argv[i + 1], "1"))) { target = atoi(argv[++i]) != 0; }
@@ -126,6 +138,13 @@ int main(int argc, char** argv) {
         else if (!strcmp(argv[i], "--device") && i + 1 < argc) device = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--out") && i + 1 < argc) { out_dir = argv[++i]; if (!out_dir.empty() && out_dir.back() != '/') out_dir += '/'; }
         else if (!strcmp(argv[i], "--shard") && i + 1 < argc) { if (sscanf(argv[++i], "%d/%d", &shard_r, &shard_n) != 2 || shard_n < 1 || shard_r < 0 || shard_r >= shard_n) { fprintf(stderr, "bad --shard\n"); return 2; } }
+        else if (!strcmp(argv[i], "--gpus") && i + 1 < argc) { devices.clear(); for (int k = 0, n = atoi(argv[++i]); k < n; k++) devices.push_back(k); }
+        else if (!strcmp(argv[i], "--devices") && i + 1 < argc) {
+            devices.clear();
+            for (const char* p = argv[++i]; *p;) { devices.push_back(atoi(p)); p += strcspn(p, ","); if (*p) p++; }
+        }
+        else if (!strcmp(argv[i], "--tile") && i + 1 < argc) { if (sscanf(argv[++i], "%dx%d", &tile_w, &tile_h) != 2 || tile_w < 1 || tile_h < 1) { fprintf(stderr, "bad --tile\n"); return 2; } }
+        else if (!strcmp(argv[i], "--resolution") && i + 1 < argc) { if (sscanf(argv[++i], "%dx%d", &res_w, &res_h) != 2 || res_w < 1 || res_h < 1) { fprintf(stderr, "bad --resolution\n"); return 2; } }
         else if (!strcmp(argv[i], "--png")) png = true;
         else if (!strcmp(argv[i], "--gpu-build")) gpu_build = true;
         else if (!strcmp(argv[i], "--consistent")) consistent = true;
@@ -133,14 +152,19 @@ int main(int argc, char** argv) {
         else scenes.push_back(argv[i]);
     }
     if (scenes.empty()) {
-        fprintf(stderr, "usage: raytracer_amd <scene.json>... [-b [0|1]] [-m [0|1]] [-c [0|1]] [--device D] [--shard R/N] [--out DIR] [--png] [--gpu-build] [--consistent]\n");
+        fprintf(stderr, "usage: raytracer_amd <scene.json>... [-b [0|1]] [-m [0|1]] [-c [0|1]] [--device D | --gpus N | --devices a,b,..] "
+                        "[--tile WxH] [--resolution WxH] [--shard R/N] [--out DIR] [--png] [--gpu-build] [--consistent]\n");
         return 2;
     }
     (void)multithreaded;
+    if (devices.empty()) devices.push_back(device);
+    device = devices[0];
+    const int n_dev = (int)devices.size();
     int rc_all = 0;
     Writer writer;
     rtx_host_scene* hs = nullptr;
-    rtx_scene* ds = nullptr;
+    std::vector<rtx_scene*> ds;                 // the scene on every device taking part
+    auto drop_device_scenes = [&ds] { for (rtx_scene* d : ds) rtx_scene_destroy(d); ds.clear(); };
     double upload_ms = 0;
     for (size_t si = 0; si < scenes.size(); si++) {
         if ((int)(si % (size_t)shard_n) != shard_r) continue;
@@ -153,6 +177,8 @@ int main(int argc, char** argv) {
                 continue;                                    // the previous scene stays loaded
             }
             hs = next;
+            // geometry replaced: the device copies belong to the previous scene, whatever happens next
+            if (!reused) drop_device_scenes();
         } else if (rtx_host_load(scenes[si].c_str(), use_bvh && !gpu_build, cull, &hs) != 0) {
             fprintf(stderr, "%s: %s\n", scenes[si].c_str(), rtx_host_last_error());
             rc_all = 1;
@@ -184,50 +210,97 @@ int main(int argc, char** argv) {
             }
             if (!ok) { rc_all = 1; continue; }
         }
-        if (reused && ds) {
+        if (reused && !ds.empty()) {
             upload_ms = 0;
-            if (rtx_scene_update_lights(ds, desc->lights, desc->n_lights) != RTX_OK) {
+            bool ok = true;
+            for (rtx_scene* d : ds) ok = ok && rtx_scene_update_lights(d, desc->lights, desc->n_lights) == RTX_OK;
+            if (!ok) {
                 fprintf(stderr, "%s: %s\n", scenes[si].c_str(), rtx_last_error());
                 rc_all = 1;
                 continue;
             }
         } else {
-            if (ds) { rtx_scene_destroy(ds); ds = nullptr; }
+            drop_device_scenes();
             auto t0 = std::chrono::high_resolution_clock::now();
-            if (rtx_scene_create(desc, device, &ds) != RTX_OK) {
-                fprintf(stderr, "%s: %s\n", scenes[si].c_str(), rtx_last_error());
-                rtx_host_free(hs);
-                return 1;                                    // no device: nothing else can work either
+            for (int k = 0; k < n_dev; k++) {
+                rtx_scene* d = nullptr;
+                if (rtx_scene_create(desc, devices[(size_t)k], &d) != RTX_OK) {
+                    fprintf(stderr, "%s: %s\n", scenes[si].c_str(), rtx_last_error());
+                    drop_device_scenes();
+                    rtx_host_free(hs);
+                    return 1;                                // no device: nothing else can work either
+                }
+                if (consistent) rtx_scene_set_consistent(d, 1);
+                ds.push_back(d);
             }
             upload_ms = std::chrono::duration<double, std::milli>(std::chrono::high_resolution_clock::now() - t0).count();
-            if (consistent) rtx_scene_set_consistent(ds, 1);
         }
         double total_ms = pre_ms;
         for (int k = 0; k < rtx_host_camera_count(hs); k++) {
             rtx_camera cam;
             char name[512];
             rtx_host_camera(hs, k, &cam, name, sizeof name);
+            if (res_w > 0) { cam.width = res_w; cam.height = res_h; }
             OutputJob job;
             job.img.resize((size_t)cam.width * cam.height * 3);
             rtx_stats st;
-            if (rtx_render(ds, &cam, cam.width, cam.height, 0, 1, job.img.data(), 0, nullptr, &st) != RTX_OK) {
-                fprintf(stderr, "%s: %s\n", scenes[si].c_str(), rtx_last_error());
-                rc_all = 1;
-                break;
+            if (n_dev == 1) {
+                if (rtx_render(ds[0], &cam, cam.width, cam.height, 0, 1, job.img.data(), 0, nullptr, &st) != RTX_OK) {
+                    fprintf(stderr, "%s: %s\n", scenes[si].c_str(), rtx_last_error());
+                    rc_all = 1;
+                    break;
+                }
+            } else {
+                // one host thread per device: its interleaved tiles into a packed buffer of its own
+                auto t0 = std::chrono::high_resolution_clock::now();
+                std::vector<std::vector<uint8_t>> packed((size_t)n_dev);
+                std::vector<rtx_stats> part((size_t)n_dev);
+                std::vector<std::string> errors((size_t)n_dev);
+                std::vector<std::thread> workers;
+                for (int r = 0; r < n_dev; r++) {
+                    const int64_t bytes = rtx_render_output_bytes(&cam, tile_w, tile_h, r, n_dev);
+                    packed[(size_t)r].resize((size_t)std::max<int64_t>(bytes, 0));
+                    workers.emplace_back([&, r] {
+                        memset(&part[(size_t)r], 0, sizeof(rtx_stats));
+                        if (packed[(size_t)r].empty()) return;
+                        if (rtx_render(ds[(size_t)r], &cam, tile_w, tile_h, r, n_dev, packed[(size_t)r].data(), 0, nullptr,
+                                       &part[(size_t)r]) != RTX_OK)
+                            errors[(size_t)r] = rtx_last_error();      // (the error text is per thread)
+                    });
+                }
+                for (std::thread& t : workers) t.join();
+                bool ok = true;
+                memset(&st, 0, sizeof st);
+                for (int r = 0; r < n_dev; r++) {
+                    if (!errors[(size_t)r].empty()) { fprintf(stderr, "%s: device %d: %s\n", scenes[si].c_str(), devices[(size_t)r], errors[(size_t)r].c_str()); ok = false; continue; }
+                    if (!packed[(size_t)r].empty() &&
+                        rtx_unpack_tiles(packed[(size_t)r].data(), cam.width, cam.height, tile_w, tile_h, r, n_dev, job.img.data()) != RTX_OK) {
+                        fprintf(stderr, "%s: %s\n", scenes[si].c_str(), rtx_last_error());
+                        ok = false;
+                    }
+                    st.rays += part[(size_t)r].rays; st.primary_rays += part[(size_t)r].primary_rays;
+                    st.shadow_rays += part[(size_t)r].shadow_rays; st.secondary_rays += part[(size_t)r].secondary_rays;
+                    st.kernel_ms = std::max(st.kernel_ms, part[(size_t)r].kernel_ms);
+                }
+                if (!ok) { rc_all = 1; break; }
+                st.total_ms = std::chrono::duration<double, std::milli>(std::chrono::high_resolution_clock::now() - t0).count();
             }
             total_ms += st.total_ms;
             job.base = out_dir + name;
             job.stem = job.base.substr(0, job.base.find_last_of('.'));
             job.width = cam.width; job.height = cam.height; job.png = png;
-            char buf[1024];
+            char buf[1536];
             snprintf(buf, sizeof buf,
                      "{\n    \"enableBackFaceCulling\": %s,\n    \"isMultiThreaded\": %s,\n"
                      "    \"preprocessingTimeMs\": %.3f,\n    \"renderTimeMs\": %.3f,\n    \"sceneName\": \"%s\",\n"
                      "    \"totalTimeMs\": %.3f,\n    \"useBVH\": %s,\n    \"device\": \"hip:%d\",\n"
                      "    \"kernelTimeMs\": %.3f,\n    \"parseTimeMs\": %.3f,\n    \"uploadTimeMs\": %.3f,\n"
-                     "    \"geometryReused\": %s\n}",
+                     "    \"geometryReused\": %s,\n    \"nGpus\": %d,\n    \"rays\": %llu,\n    \"MraysPerS\": %.3f,\n"
+                     "    \"width\": %d,\n    \"height\": %d\n}",
                      cull ? "true" : "false", multithreaded ? "true" : "false", pre_ms, st.total_ms, name, total_ms,
-                     use_bvh ? "true" : "false", device, st.kernel_ms, parse_ms, upload_ms, reused ? "true" : "false");
+                     use_bvh ? "true" : "false", device, st.kernel_ms, parse_ms, upload_ms, reused ? "true" : "false",
+                     n_dev, (unsigned long long)st.rays, st.total_ms > 0 ? (double)st.rays / st.total_ms / 1e3 : 0.0,
+                     cam.width, cam.height);
             job.results = buf;
             writer.push(std::move(job));
             if (!quiet)
@@ -236,7 +309,7 @@ int main(int argc, char** argv) {
                        reused ? " (geometry kept)" : "");
         }
     }
-    if (ds) rtx_scene_destroy(ds);
+    drop_device_scenes();
     if (hs) rtx_host_free(hs);
     if (!writer.finish()) rc_all = 1;
     return rc_all;

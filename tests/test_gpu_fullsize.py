@@ -4,6 +4,9 @@ deep BVH; 10 000 instances) rendered by the HIP core through its C-ABI.
 The CPU oracle cannot render a full frame of these in test time, so two kinds of check
 are used:
 
+* the full-size *frame* itself against the CPU restatement on all host threads and against the
+  picture the compiled reference writes for the same scene file, for the workloads whose
+  reference frame takes seconds (`test_full_frame_matches_oracle_and_reference`);
 * the full-size *scene* on a reduced view (same camera, image reduced by an integer
   factor): every primary hit must equal the oracle's bit for bit, the image must meet the
   parity bar, and the closest-hit query counts must agree;
@@ -63,6 +66,33 @@ def test_full_size_scene_matches_oracle_on_reduced_view(workloads, name, factor)
     assert len(ck.compare_hits(hits2, o_hits, allow_src_unknown=False)) == 0
     same, mx = ck.image_diff(rgb2, o_rgb)
     assert mx <= MAX_DELTA and same >= MIN_SAME, f"{name} (default mode): {same:.5f} identical, max delta {mx}"
+
+
+@pytest.mark.parametrize("name,factor", [("dragon_metal", 1), ("marching_dragons", 1), ("metal_glass_plates", 1),
+                                         ("camera_around_david", 1), ("grass_desert", 4)])
+def test_full_frame_matches_oracle_and_reference(workloads, name, factor):
+    """The frame the benchmark times (grass_desert: the same view at 1/4 of the resolution in
+    both directions -- the reference's linear instance loop needs minutes for the 4K frame):
+    every primary-hit record equals the oracle's, the picture meets the parity bar against the
+    oracle and against the PPM the unmodified reference renderer writes (raytracer.cpp:45-51,78-80)."""
+    import os
+    threads = min(16, os.cpu_count() or 1)
+    hs, ds = workloads(name)
+    cam, _ = hs.camera(0)
+    view = bench.reduced_camera(cam, factor) if factor > 1 else cam
+    rgb, hits, st = ds.render(view, want_hits=True)
+    o_rgb, o_hits, o_ctr, _ = ck.oracle_render(hs.desc, view, nthreads=threads)
+    bad = ck.compare_hits(hits, o_hits, allow_src_unknown=False)
+    assert len(bad) == 0, f"{name}: {len(bad)} primary hits differ"
+    same, mx = ck.image_diff(rgb, o_rgb)
+    assert mx <= MAX_DELTA and same >= MIN_SAME, f"{name}: {same:.5f} identical, max delta {mx}"
+    assert st["rays"] == o_ctr["rays"]            # (ray counts need no device counters)
+    if os.access(ck.REF_BIN, os.X_OK):
+        _, ref_img = bench.cpu_reference_baseline(hs.path, 1, sample_f=factor, runs=1)
+        assert ref_img is not None and ref_img.shape == rgb.shape
+        same, mx = ck.image_diff(rgb, ref_img)
+        assert mx <= MAX_DELTA and same >= MIN_SAME, f"{name} vs reference PPM: {same:.5f} identical, max delta {mx}"
+        assert np.array_equal(o_rgb, ref_img), "the oracle's frame is the reference's, byte for byte"
 
 
 @pytest.mark.parametrize("name,tile", [("dragon_metal", (64, 64)), ("grass_desert", (128, 72))])
