@@ -3,7 +3,8 @@
 #
 #   make            -> host library, device library (gfx950), CLI, oracle checkers
 #   make product    -> only what ships: librtx_host.so, librtx_amd.so, raytracer_amd
-#   make checkers   -> oracle/librt_oracle.so and, when /root/reference exists, oracle/_ref/*
+#   make checkers   -> oracle/librt_oracle.so and, when /root/reference exists, oracle/_ref/* (the compiled
+#                      reference, its dumper, and the reference-side bridge's test program)
 HIPCC   ?= /opt/rocm/bin/hipcc
 CXX     ?= g++
 ARCH    ?= gfx950
@@ -43,8 +44,8 @@ $(LIBDIR)/raytracer_amd: $(HOSTSRC)/main.cpp $(LIBDIR)/librtx_host.so $(LIBDIR)/
 	$(CXX) $(HOSTFLAGS) -pthread -o $@ $(HOSTSRC)/main.cpp -L$(LIBDIR) -lrtx_host -lrtx_amd \
 	    -Wl,-rpath,'$$ORIGIN' -Wl,-rpath-link,/opt/rocm/lib
 
-checkers:
-	$(MAKE) -C oracle oracle ref
+checkers: product
+	$(MAKE) -C oracle oracle ref bridge
 
 clean:
 	rm -rf $(LIBDIR)
