@@ -869,6 +869,13 @@ int render_frame(rtx_scene* sc, const rtx_camera* cam, int32_t tw, int32_t th, i
         // every generation's drained waves (a kernel variant of its own; see k_trace)
         launch.chunk_max = sc->dev.n_insts >= 256 ? RTX_CHUNK_INSTANCED : RTX_CHUNK; launch.pad_launch = 0;
         launch.wide_old = (launch.wide_ok && sc->dev.n_insts < 256 && !getenv("RTX_AMD_NO_WIDE_OLD")) ? 1u : 0u;
+        {
+            // RTX_AMD_QUORUM=node,leaf,eval,fin (development aid)
+            static const char* qenv = getenv("RTX_AMD_QUORUM");
+            int q[4] = {RTX_Q_NODE, RTX_Q_LEAF, RTX_Q_EVAL, RTX_Q_FIN};
+            if (qenv) sscanf(qenv, "%d,%d,%d,%d", &q[0], &q[1], &q[2], &q[3]);
+            for (int k = 0; k < 4; k++) launch.quorum[k] = (uint32_t)std::max(1, std::min(64, q[k]));
+        }
         HIP_TRY(hipMemcpyAsync(M.launch, &launch, sizeof launch, hipMemcpyHostToDevice, sc->stream));
         const Launch* lp = (const Launch*)M.launch;
 
@@ -989,6 +996,8 @@ int render_frame(rtx_scene* sc, const rtx_camera* cam, int32_t tw, int32_t th, i
                         "mean wave lifetime %.1f us at 2.4 GHz: stepping %.1f, servicing %.1f\n", gen, c.rays, c.section[0], c.waves,
                         (double)c.clk_traverse / steps, c.service_passes, (double)c.clk_service / std::max(1ull, c.service_passes),
                         (double)c.clk_total / waves / 2400.0, (double)c.clk_traverse / waves / 2400.0, (double)c.clk_service / waves / 2400.0);
+                fprintf(stderr, "[rtx]        ticks per step: top of loop %.0f, request + fetch %.0f, the rest (processing) %.0f; fetching lanes per step %.1f\n",
+                        (double)c.clk_pop / steps, (double)c.clk_fetch / steps, ((double)c.clk_traverse - (double)c.clk_fetch) / steps, c.section[7] / steps);
                 fprintf(stderr, "[rtx]        lanes per step: traversing %.1f, evaluating objects %.1f, walking the bitmap %.1f, finishing hits %.1f, "
                         "finished %.1f, empty %.1f\n", c.section[1] / steps, c.section[2] / steps, c.section[3] / steps, c.section[4] / steps,
                         c.section[5] / steps, c.section[6] / steps);

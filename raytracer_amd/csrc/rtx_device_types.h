@@ -217,6 +217,9 @@ struct Launch {
     uint32_t wide_old;
     // Largest number of rays a wave of the trace kernel claims at once.
     uint32_t chunk_max, pad_launch;
+    // Lanes that must be waiting for a kind of work before the trace kernel runs it: box tests of
+    // nodes, triangle tests of leaves, object evaluations, hit finishing.
+    uint32_t quorum[4];
 };
 
 struct Counters {

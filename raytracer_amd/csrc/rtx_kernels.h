@@ -199,37 +199,38 @@ typedef __attribute__((address_space(3))) v2d lds_v2d;
 typedef __attribute__((address_space(1))) v4i glob_v4i;
 
 // Per-wave context: this wave's 64 LDS rows and the lane number.
-struct Wave { lds_double* rows; unsigned lane; };
+typedef __attribute__((address_space(3))) int lds_int;
+typedef __attribute__((address_space(3))) v4i lds_v4i;
+// keys: 64 dwords of LDS per wave through which the lanes learn the keys of the owners they serve
+struct Wave { lds_double* rows; lds_int* keys; unsigned lane; };
 
 // Wave-cooperative gather of one 256-byte record per requesting lane into that lane's LDS row.
-// `key` names the record by its offset in 128-byte
-// units from `blas` (-1 = no request): a collapsed node, or a pair of triangle records.
+// `key` names the record by its offset in 128-byte units from `blas` (-1 = no request; the
+// lane's row then keeps what it holds): a collapsed node, a pair of triangle records, half an
+// object record.
 //
 // Sixteen lanes read one record as sixteen adjacent 16-byte pieces, so one load instruction
 // touches 4 records x 256 contiguous bytes instead of 64 scattered pieces.  The loads are
 // LDS-DMA (global_load_lds_dwordx4, destination = wave-uniform base + 16*lane): in round g
 // lane l serves owner 4g + l/16, and the round fills the rows of owners 4g..4g+3.  The lanes
-// learn their owners' keys through the (still unused) row memory: owner w stores its key at
+// learn their owners' keys through 64 dwords of LDS (Wave::keys): owner w stores its key at
 // dword (w & 3)*16 + (w >> 2), so the sixteen keys a lane needs are 64 contiguous bytes.
 // To keep the owners' later 16-byte row reads free of bank conflicts the pieces are stored
 // XOR-swizzled: slot s of owner w holds piece s ^ (w & 15) -- applied to the *source* address
 // here and to the slot index in row_read.  Must be executed by every lane of the wave.
-typedef __attribute__((address_space(3))) int lds_int;
-typedef __attribute__((address_space(3))) v4i lds_v4i;
 RTX_DEV void coop_fetch(const Wave& wv, int key, const char* __restrict__ blas) {
     const unsigned lane = wv.lane, quarter = lane >> 4, slot = lane & 15u;
-    ((lds_int*)wv.rows)[(lane & 3u) * 16u + (lane >> 2)] = key;
+    wv.keys[(lane & 3u) * 16u + (lane >> 2)] = key;
     __builtin_amdgcn_wave_barrier();
     int okeys[16];
     {
-        const lds_v4i* kp = (const lds_v4i*)wv.rows + quarter * 4u;
+        const lds_v4i* kp = (const lds_v4i*)wv.keys + quarter * 4u;
 #pragma unroll
         for (int q = 0; q < 4; q++) {
             const v4i v = kp[q];
             okeys[4 * q] = v.x; okeys[4 * q + 1] = v.y; okeys[4 * q + 2] = v.z; okeys[4 * q + 3] = v.w;
         }
     }
-    // the keys must have left the row memory before the first record lands in it
     __builtin_amdgcn_s_waitcnt(0xC07F);          // lgkmcnt(0); vmcnt and expcnt left at "no wait"
     __builtin_amdgcn_wave_barrier();
     // Source address of this lane's piece in round g: piece = slot ^ ((4g + quarter) & 15)
@@ -412,7 +413,7 @@ RTX_DEV void free_tri_hit(const Scene& S, V3 ro, V3 rd, int index, double& t_min
 #define RTX_SCATTER_SHIFT_THIN 0           // log2 of their group size
 #endif
 #ifndef RTX_LDS_OBJS
-#define RTX_LDS_OBJS 12              // object records (512 B each) kept in LDS per block: the first so many of the scene
+#define RTX_LDS_OBJS 10              // object records (512 B each) kept in LDS per block: the first so many of the scene
 #endif
 #ifndef RTX_SCATTER0_SHIFT
 #define RTX_SCATTER0_SHIFT 6         // generation 0: whole 8x8 pixel blocks (64 items) are scattered

@@ -17,25 +17,36 @@
 
 namespace rtxdev {
 
-// Lane states.  Everything from ST_ADV up is a ray at work.
+// Lane states.  Everything from ST_ADV up is a ray at work.  A state either needs a record (the
+// next step fetches it) or has it in the lane's LDS row and waits for its kind of work to be run.
 enum { ST_EMPTY = 0,   // no ray
        ST_DONE = 1,    // ray finished, to be retired by the next service pass
        ST_ADV = 2,     // an object has been dealt with: pick the next one (registers only, at the top of the loop)
-       ST_EVAL = 3,    // object L.obj's record is at hand (block's LDS copy, or fetched by the last step): evaluate it at the top of the loop
-       ST_TRAV = 4,    // inside a traversal job: record cur_ref (node if cur_cnt == 0, else leaf triangles)
-       ST_OBJ = 5,     // object L.obj is next: record = first half of its object record
-       ST_SUM = 6,     // instance replay: taking summary word L.sword of the candidate bitmap
-       ST_WORD = 7,    //                  taking bitmap word L.word
-       ST_CLEAN = 8,   // decided shadow ray: clearing the candidates it will not replay
-       ST_FIN = 9,     // job ended with a hit: record = the winning triangle
-       ST_FIN2 = 10 }; //   ... of a transformed object: record = second half of the object record
+       ST_EVAL = 3,    // object L.obj's record is at hand (block's LDS copy, or the lane's row): to be evaluated at the top of the loop
+       ST_TRAV = 4,    // inside a traversal job, needs record cur_ref (node if cur_cnt == 0, else leaf triangles)
+       ST_TRAV_R = 5,  //   ... and has it
+       ST_OBJ = 6,     // object L.obj is next: needs the first half of its object record
+       ST_SUM = 7,     // instance replay: taking summary word L.sword of the candidate bitmap
+       ST_WORD = 8,    //                  taking bitmap word L.word
+       ST_CLEAN = 9,   // decided shadow ray: clearing the candidates it will not replay
+       ST_FIN = 10,    // job ended with a hit: needs the winning triangle's record
+       ST_FIN_R = 11,  //   ... and has it
+       ST_FIN2 = 12,   // ... of a transformed object: needs the second half of the object record
+       ST_FIN2_R = 13 };
 
 #ifndef RTX_SERVICE_IDLE
 #define RTX_SERVICE_IDLE 16          // idle lanes (empty or finished) that trigger a service pass
 #endif
-#ifndef RTX_FIN_QUORUM
-#define RTX_FIN_QUORUM 6             // hits are finished when this many lanes have one (or little else is left to do):
-#endif                               // a branch of the step costs the same whether one lane takes it or sixty
+// A kind of work (box tests of a node, triangle tests of a leaf, evaluating an object, finishing a
+// hit) costs the wave the same instructions whether one lane takes part or sixty, and the kernel is
+// bound by instruction issue: a kind is run when this many lanes are waiting for it (fewer when
+// the wave has few rays at work: a third of them; always once the generation has no fresh rays).
+#ifndef RTX_Q_NODE
+#define RTX_Q_NODE 16
+#define RTX_Q_LEAF 12
+#define RTX_Q_EVAL 12
+#define RTX_Q_FIN 8
+#endif
 #ifndef RTX_EVAL_REPS
 #define RTX_EVAL_REPS 3              // objects a lane may evaluate from the block's LDS copy before the step goes on
 #endif
@@ -291,6 +302,8 @@ k_trace(const Launch* __restrict__ Lp, GenCtrl* ctrl, const int gen, double* __r
     Wave wv;
     // (wave-uniform by construction; saying so keeps the LDS-DMA destinations in scalar registers)
     wv.rows = (lds_double*)(size_t)__builtin_amdgcn_readfirstlane((int)(size_t)(lds_double*)&lds_rows[threadIdx.x >> 6][0]);
+    __shared__ int lds_keys[4][64];
+    wv.keys = (lds_int*)(size_t)__builtin_amdgcn_readfirstlane((int)(size_t)(lds_int*)&lds_keys[threadIdx.x >> 6][0]);
     wv.lane = lane_id();
     const unsigned lane = wv.lane;
     GenCtrl* me = ctrl + gen;
@@ -349,6 +362,9 @@ k_trace(const Launch* __restrict__ Lp, GenCtrl* ctrl, const int gen, double* __r
     L.o = mk(0, 0, 0); L.d = mk(0, 0, 1); L.wix = L.wiy = L.wiz = 0.0; L.orig_t_min = 0.0;
     L.it = 0; L.word = 0; L.whi = -1; L.bits = 0u; L.sword = 0; L.sbits = 0u; L.age = 0; L.oflags = 0; L.omat = -1; L.omesh = 0;
 
+    const int q_node = (int)Lp->quorum[0], q_leaf = (int)Lp->quorum[1], q_eval = (int)Lp->quorum[2], q_fin = (int)Lp->quorum[3];
+    bool run_all = false;           // wave-uniform: the last step made no progress, or the generation has drained
+
     while (true) {
         RecOut out;
         out.rec = (RTX_GLOBAL Hit*)Lp->hb.recs + L.slot; out.on = L.is_shadow == 0; out.ids = (gen == 0 && aov != nullptr);
@@ -356,9 +372,15 @@ k_trace(const Launch* __restrict__ Lp, GenCtrl* ctrl, const int gen, double* __r
         // the last step into the lane's row (still intact: nothing has been fetched since), or one of
         // the scene's first objects in the block's LDS copy, which costs no step at all; a lane may
         // get through several of those here.
+        const long long t0 = COUNT ? clock64() : 0;
+        bool progress_top = __ballot(L.state == ST_ADV) != 0ull;
         for (int rep = 0; rep < RTX_EVAL_REPS; rep++) {
             if (L.state == ST_ADV) advance<COUNT, FAST>(S, oc, L, out, inst_bits);
-            if (__ballot(L.state == ST_EVAL) == 0ull) break;
+            const int n_eval = __popcll(__ballot(L.state == ST_EVAL));
+            if (n_eval == 0) break;
+            const int n_at_work = __popcll(__ballot(L.state >= ST_ADV));
+            if (!(run_all || drained || n_eval >= min(q_eval, (n_at_work + 2) / 3))) break;
+            progress_top = true;
             if (L.state == ST_EVAL) {
                 RecView E;
                 if (L.obj < oc.n) { E.base = (const lds_v2d*)(lds_double*)lds_objs + (unsigned)L.obj * (unsigned)(sizeof(Obj) / 16); E.sw = 0u; }
@@ -426,6 +448,7 @@ k_trace(const Launch* __restrict__ Lp, GenCtrl* ctrl, const int gen, double* __r
                 if (!go) L.state = ST_ADV;
             }
         }
+        if (COUNT) tl.clk_pop += (unsigned long long)(clock64() - t0);
         const int st = L.state;
         const unsigned long long m_work = __ballot(st >= ST_ADV);
         const unsigned long long m_done = __ballot(st == ST_DONE);
@@ -524,42 +547,22 @@ k_trace(const Launch* __restrict__ Lp, GenCtrl* ctrl, const int gen, double* __r
         // the generation has drained and this wave holds its last few jobs: finish them wave-wide
         if (!COUNT && WIDE != 0 && drained && __popcll(m_work) <= wide_lanes) {
             const unsigned long long m_old = __ballot(st == ST_TRAV && (WIDE == 2 || L.age >= wide_age));
-            if (m_old != 0ull) {
+            // (the wave-wide traversal uses every lane's row: no lane may be holding a record in its own)
+            const bool rows_free = __ballot(st == ST_TRAV_R || st == ST_EVAL || st == ST_FIN_R || st == ST_FIN2_R) == 0ull;
+            if (m_old != 0ull && rows_free) {
                 wide_jobs<COUNT, FAST>(S, oc, wv, L, stk, inst_bits, m_old);
                 continue;
             }
         }
 
         // ---- one step -----------------------------------------------------------------------------
-        const bool trav = st == ST_TRAV;
-        const bool at_leaf = trav && L.cur_cnt > 0;
         const long long s0 = COUNT ? clock64() : 0;
-        if (COUNT) {
-            const int nl = __popcll(__ballot(at_leaf)), nj = __popcll(__ballot(trav));
-            // lanes per state in this step (development aid, printed with RTX_AMD_GEN_TIMING)
-            const int n_obj = __popcll(__ballot(st == ST_OBJ)), n_bits = __popcll(__ballot(st == ST_SUM || st == ST_WORD || st == ST_CLEAN));
-            const int n_fin_all = __popcll(__ballot(st == ST_FIN || st == ST_FIN2));
-            if (lane == 0) {
-                if (nj > nl) { tl.inner_steps++; tl.inner_lanes += (unsigned)(nj - nl); }
-                if (nl) { tl.leaf_steps++; tl.leaf_lanes += (unsigned)nl; }
-                tl.sec[0]++; tl.sec[1] += (unsigned)nj; tl.sec[2] += (unsigned)n_obj; tl.sec[3] += (unsigned)n_bits; tl.sec[4] += (unsigned)n_fin_all;
-                tl.sec[5] += (unsigned)__popcll(m_done); tl.sec[6] += (unsigned)__popcll(m_empty);
-            }
-        }
-        // rays with an axis-parallel component are rare: the wave takes the general box test
-        // only when one of its traversing lanes has one
-        const bool any_par = __ballot(trav && (L.par & 7) != 0) != 0ull;
-
-        // the record this lane's state needs (-1: none, or it is in the block's LDS copy)
-        // (hits are finished in batches: see RTX_FIN_QUORUM)
-        const int n_fin = __popcll(__ballot(st == ST_FIN || st == ST_FIN2));
-        const bool run_fin = n_fin >= RTX_FIN_QUORUM || __popcll(m_work) - n_fin < 16;
-        const bool fin = run_fin && st == ST_FIN, fin2 = run_fin && st == ST_FIN2;
-        const bool in_lds = fin2 && L.obj < oc.n;
+        // the record this lane's state needs (-1: none, it has one, or it is in the block's LDS copy)
         int key = -1;
-        if (trav) key = L.cur_ref;
-        else if (fin) key = L.btri;
-        else if (st == ST_OBJ || (fin2 && !in_lds)) key = S.obj_key0 + 4 * L.obj + (fin2 ? 2 : 0);
+        if (st == ST_TRAV) key = L.cur_ref;
+        else if (st == ST_FIN) key = L.btri;
+        else if (st == ST_OBJ) key = S.obj_key0 + 4 * L.obj;
+        else if (st == ST_FIN2 && L.obj >= oc.n) key = S.obj_key0 + 4 * L.obj + 2;
         // bitmap walkers: one atomic exchange, taking the word and leaving it clear; the value is
         // there when the step's records are.  A lane that fetches the record of a bitmap word's last
         // candidate takes the next word (or summary word) in the same step.
@@ -578,13 +581,17 @@ k_trace(const Launch* __restrict__ Lp, GenCtrl* ctrl, const int gen, double* __r
         }
         if (pending_is == 2) pending = atomicExch(inst_bits + L.sword, 0u);          // summary words come first in the lane's area
         else if (pending_is == 1) pending = atomicExch(inst_bits + n_summary + L.word, 0u);
+        const unsigned long long m_fetch = __ballot(key != -1);
+        bool progress = progress_top || m_fetch != 0ull || __ballot(pending_is != 0) != 0ull;
 
         // A wave with only a lane or two still at work is on the frame's critical path (the
         // longest rays of a generation); it loads the records directly, one memory round trip
-        // without the detour through LDS.  Otherwise the wave fetches cooperatively.
+        // without the detour through the other lanes.  Otherwise the wave fetches cooperatively.
         RecView R;
         R.base = (const lds_v2d*)(wv.rows + lane * RTX_ROW_DOUBLES); R.sw = lane & 15u;
-        if (__popcll(m_work) <= RTX_SPARSE_LANES) {
+        if (m_fetch == 0ull) {
+            // (no record to fetch: every lane at work has its record and waits for its kind's turn)
+        } else if (__popcll(m_work) <= RTX_SPARSE_LANES) {
             if (key != -1) {
                 const RTX_GLOBAL v2d* gp = (const RTX_GLOBAL v2d*)(blas + ((size_t)(unsigned)key << 7));
                 lds_v2d* row = (lds_v2d*)(wv.rows + lane * RTX_ROW_DOUBLES);
@@ -594,14 +601,61 @@ k_trace(const Launch* __restrict__ Lp, GenCtrl* ctrl, const int gen, double* __r
         } else {
             coop_fetch(wv, key, blas);
         }
-        if (in_lds) {
+        if (COUNT) tl.clk_fetch += (unsigned long long)(clock64() - s0);
+        // what arrived
+        if (st == ST_TRAV) L.state = ST_TRAV_R;
+        else if (st == ST_FIN) L.state = ST_FIN_R;
+        else if (st == ST_FIN2) L.state = ST_FIN2_R;
+        else if (st == ST_OBJ) {
+            L.state = ST_EVAL;                   // evaluated at the top of the loop
+            if (pending_is == 1) L.bits = pending;
+            else if (pending_is == 2) L.sbits = pending;
+        } else if (st == ST_SUM) { L.sbits = pending; L.state = ST_ADV; }
+        else if (st == ST_WORD) { L.bits = pending; L.state = ST_ADV; }
+        else if (st == ST_CLEAN) {
+            unsigned sb = pending;
+            while (sb != 0u) {
+                const int w = L.sword * 32 + (__ffs((int)sb) - 1);
+                sb &= sb - 1u;
+                __hip_atomic_store(inst_bits + n_summary + w, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (L.sword >= L.whi) L.state = ST_DONE;
+        }
+
+        // which kinds of work are run in this step
+        const int s2 = L.state;
+        const bool is_node = s2 == ST_TRAV_R && L.cur_cnt == 0, at_leaf = s2 == ST_TRAV_R && L.cur_cnt > 0;
+        const int n_node = __popcll(__ballot(is_node)), n_leaf = __popcll(__ballot(at_leaf));
+        const int n_fin1 = __popcll(__ballot(s2 == ST_FIN_R)), n_fin2 = __popcll(__ballot(s2 == ST_FIN2_R));
+        const int q_cap = (__popcll(m_work) + 2) / 3;
+        const bool everything = run_all || drained;
+        const bool run_node = n_node > 0 && (everything || n_node >= min(q_node, q_cap));
+        const bool run_leaf = n_leaf > 0 && (everything || n_leaf >= min(q_leaf, q_cap));
+        const bool run_fin1 = n_fin1 > 0 && (everything || n_fin1 >= min(q_fin, q_cap));
+        const bool run_fin2 = n_fin2 > 0 && (everything || n_fin2 >= min(q_fin, q_cap));
+        progress = progress || run_node || run_leaf || run_fin1 || run_fin2;
+        if (COUNT && lane == 0) {
+            if (run_node) { tl.inner_steps++; tl.inner_lanes += (unsigned)n_node; }
+            if (run_leaf) { tl.leaf_steps++; tl.leaf_lanes += (unsigned)n_leaf; }
+            tl.sec[0]++; tl.sec[1] += (unsigned)(n_node + n_leaf); tl.sec[2] += (unsigned)__popcll(__ballot(st == ST_OBJ || st == ST_EVAL));
+            tl.sec[3] += (unsigned)__popcll(__ballot(pending_is != 0 && st != ST_OBJ)); tl.sec[4] += (unsigned)(n_fin1 + n_fin2);
+            tl.sec[5] += (unsigned)__popcll(m_done); tl.sec[6] += (unsigned)__popcll(m_empty);
+            tl.sec[7] += (unsigned)__popcll(m_fetch);
+        }
+        const bool trav = (is_node && run_node) || (at_leaf && run_leaf);
+        const bool fin = run_fin1 && s2 == ST_FIN_R, fin2 = run_fin2 && s2 == ST_FIN2_R;
+        if (fin2 && L.obj < oc.n) {
             R.base = (const lds_v2d*)(lds_double*)lds_objs + (unsigned)L.obj * (unsigned)(sizeof(Obj) / 16) + 16u;
             R.sw = 0u;
         }
+        // rays with an axis-parallel component are rare: the wave takes the general box test
+        // only when one of its traversing lanes has one
+        const bool any_par = __ballot(trav && (L.par & 7) != 0) != 0ull;
 
         if (trav) {
             bool need_pop = false;
             L.age++;
+            L.state = ST_TRAV;                   // (needs its next record, unless the job ends below)
             Slab sl;
             sl.ox = L.ro.x; sl.oy = L.ro.y; sl.oz = L.ro.z; sl.ix = L.ix; sl.iy = L.iy; sl.iz = L.iz; sl.par = L.par & 7;
             if (!at_leaf) {
@@ -753,10 +807,6 @@ k_trace(const Launch* __restrict__ Lp, GenCtrl* ctrl, const int gen, double* __r
                 }
                 if (!live) job_end<COUNT, FAST>(oc, L);
             }
-        } else if (st == ST_OBJ) {
-            L.state = ST_EVAL;                   // the record is in the lane's row now: evaluated at the top of the loop
-            if (pending_is == 1) L.bits = pending;
-            else if (pending_is == 2) L.sbits = pending;
         } else if (fin) {
             // ---- what rayHitsMesh does after bvh->traverse returned a hit (utils.cpp:533-668), first
             // part: the fields the winning triangle test wrote (utils.cpp:370-381, bvh.cpp:162).
@@ -843,22 +893,10 @@ k_trace(const Launch* __restrict__ Lp, GenCtrl* ctrl, const int gen, double* __r
                 L.hit = 1;
             }
             L.state = ST_ADV;
-        } else if (st == ST_SUM) {
-            L.sbits = pending;
-            L.state = ST_ADV;
-        } else if (st == ST_WORD) {
-            L.bits = pending;
-            L.state = ST_ADV;
-        } else if (st == ST_CLEAN) {
-            unsigned sb = pending;
-            while (sb != 0u) {
-                const int w = L.sword * 32 + (__ffs((int)sb) - 1);
-                sb &= sb - 1u;
-                __hip_atomic_store(inst_bits + n_summary + w, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            if (L.sword >= L.whi) L.state = ST_DONE;
         }
         __builtin_amdgcn_wave_barrier();
+        // a step in which nothing moved (every lane waiting for a quorum that cannot form): run every kind next time
+        run_all = !progress;
         if (COUNT) tl.clk_trav += (unsigned long long)(clock64() - s0);
     }
 
@@ -868,7 +906,7 @@ k_trace(const Launch* __restrict__ Lp, GenCtrl* ctrl, const int gen, double* __r
                                     tl.world_box, tl.obj_trav, tl.tlas_visits, tl.inner_steps, tl.inner_lanes,
                                     tl.leaf_steps, tl.leaf_lanes, l0 ? tl.passes : 0u, l0 ? tl.clk_trav : 0ull,
                                     l0 ? tl.clk_serv : 0ull, l0 ? (unsigned long long)(clock64() - clk_begin) : 0ull,
-                                    l0 ? 1ull : 0ull, 0ull, 0ull, 0ull, 0ull,
+                                    l0 ? 1ull : 0ull, l0 ? tl.clk_fetch : 0ull, l0 ? tl.clk_pop : 0ull, 0ull, 0ull,
                                     tl.sec[0], tl.sec[1], tl.sec[2], tl.sec[3], tl.sec[4], tl.sec[5], tl.sec[6], tl.sec[7]};
 #pragma unroll
         for (int k = 0; k < 30; k++) {
