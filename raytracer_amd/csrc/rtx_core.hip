@@ -16,7 +16,7 @@
 
 #include "rtx_amd.h"
 #include "rtx_device_types.h"
-#include "rtx_trace.h"
+#include "rtx_kernels.h"
 
 using namespace rtxdev;
 
@@ -78,7 +78,7 @@ struct rtx_scene {
     bool consistent = false;
     int64_t queue_limit = (int64_t)32 << 30;
     uint32_t queue_capacity = 0;    // rays per queue, grows on overflow and is then kept
-    DevBuf materials, lights, xforms, planes, spheres, ftris, meshes, insts, blas, tri_vn;
+    DevBuf materials, lights, xforms, planes, spheres, ftris, meshes, insts, objs, blas, tri_vn;
     DevBuf accum, rgb, aov, ctrl, counters, queue[2], hitbuf, launch, stacks, inst_bits;
     size_t inst_bits_cleared = 0;   // bytes of inst_bits known to be all zero
     int record_levels = 0;          // deepest chain of records in any BLAS or the TLAS
@@ -505,6 +505,7 @@ int build_scene(rtx_scene& sc, const rtx_scene_desc& d) {
     for (int i = 0; i < d.n_meshes; i++) fill_obj(objs[(size_t)i], i, F.meshes[(size_t)i].xform, F.meshes[(size_t)i].material);
     for (int i = 0; i < d.n_instances; i++)
         fill_obj(objs[(size_t)d.n_meshes + (size_t)i], insts[(size_t)i].base_mesh, insts[(size_t)i].xform, insts[(size_t)i].material);
+    HIP_TRY(sc.objs.upload(objs));        S.objs = (const Obj*)sc.objs.p;
 
     HIP_TRY(sc.materials.upload(mats));   S.materials = (const Material*)sc.materials.p;
     HIP_TRY(sc.lights.upload(lights));    S.lights = (const Light*)sc.lights.p;
@@ -515,17 +516,11 @@ int build_scene(rtx_scene& sc, const rtx_scene_desc& d) {
     HIP_TRY(sc.meshes.upload(F.meshes));  S.meshes = (const Mesh*)sc.meshes.p;
     HIP_TRY(sc.insts.upload(insts));      S.insts = (const Inst*)sc.insts.p;
     {
-        // nodes, triangles (the padding triangle keeps the count's parity irrelevant), object records
-        const size_t nb = F.nodes.size() * sizeof(Node4), tb = F.tris.size() * sizeof(Tri), ob = objs.size() * sizeof(Obj);
-        if ((nb + tb + ob + 256) / 128 > (size_t)INT_MAX) return fail(RTX_ELIMIT, "scene records larger than 256 GB");
-        HIP_TRY(sc.blas.ensure(nb + tb + ob + 256));       // (a fetch is 256 bytes from any key)
+        const size_t nb = F.nodes.size() * sizeof(Node4), tb = F.tris.size() * sizeof(Tri);
+        HIP_TRY(sc.blas.ensure(nb + tb));
         if (nb) HIP_TRY(hipMemcpy(sc.blas.p, F.nodes.data(), nb, hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy((char*)sc.blas.p + nb, F.tris.data(), tb, hipMemcpyHostToDevice));
-        if (ob) HIP_TRY(hipMemcpy((char*)sc.blas.p + nb + tb, objs.data(), ob, hipMemcpyHostToDevice));
-        HIP_TRY(hipMemset((char*)sc.blas.p + nb + tb + ob, 0, 256));
         S.blas = (const char*)sc.blas.p;
-        S.objs = (const Obj*)((const char*)sc.blas.p + nb + tb);
-        S.obj_key0 = (int32_t)((nb + tb) / 128);
     }
     if (F.any_vn) { HIP_TRY(sc.tri_vn.upload(F.tri_vn)); S.tri_vn = (const double*)sc.tri_vn.p; }
     else {
@@ -860,22 +855,16 @@ int render_frame(rtx_scene* sc, const rtx_camera* cam, int32_t tw, int32_t th, i
         launch.hb = make_hitbuf(M.hitbuf, M.hit_capacity);
         launch.stacks = M.stacks;
         launch.inst_bits = M.inst_bits; launch.inst_words = inst_words;
-        // idle lanes (no ray, or a finished one to retire) that make a wave run a service pass
-        static const int service_idle = getenv("RTX_AMD_SERVICE_IDLE") ? atoi(getenv("RTX_AMD_SERVICE_IDLE")) : RTX_SERVICE_IDLE;
-        launch.service_threshold = (uint32_t)std::max(1, std::min(64, service_idle));
+        // A service pass lasts as long as its slowest lane.  Replaying instance candidates makes
+        // that long (a chain of dependent loads per candidate), so scenes with many instances
+        // gather more lanes per pass.
+        launch.service_threshold = sc->dev.n_insts >= 256 ? RTX_SERVICE_THRESHOLD_INSTANCED : RTX_SERVICE_THRESHOLD;
         // wave-wide traversal of a drained generation's last jobs: its visiting-order keys hold 26 record levels
         launch.wide_ok = (sc->record_levels <= 26 && !getenv("RTX_AMD_NO_WIDE")) ? 1u : 0u;
         // ... and, in scenes that are not dominated by instance replay, of the long-running jobs of
         // every generation's drained waves (a kernel variant of its own; see k_trace)
         launch.chunk_max = sc->dev.n_insts >= 256 ? RTX_CHUNK_INSTANCED : RTX_CHUNK; launch.pad_launch = 0;
         launch.wide_old = (launch.wide_ok && sc->dev.n_insts < 256 && !getenv("RTX_AMD_NO_WIDE_OLD")) ? 1u : 0u;
-        {
-            // RTX_AMD_QUORUM=node,leaf,eval,fin (development aid)
-            static const char* qenv = getenv("RTX_AMD_QUORUM");
-            int q[4] = {RTX_Q_NODE, RTX_Q_LEAF, RTX_Q_EVAL, RTX_Q_FIN};
-            if (qenv) sscanf(qenv, "%d,%d,%d,%d", &q[0], &q[1], &q[2], &q[3]);
-            for (int k = 0; k < 4; k++) launch.quorum[k] = (uint32_t)std::max(1, std::min(64, q[k]));
-        }
         HIP_TRY(hipMemcpyAsync(M.launch, &launch, sizeof launch, hipMemcpyHostToDevice, sc->stream));
         const Launch* lp = (const Launch*)M.launch;
 
@@ -991,17 +980,40 @@ int render_frame(rtx_scene* sc, const rtx_camera* cam, int32_t tw, int32_t th, i
         if (getenv("RTX_AMD_GEN_TIMING"))
             for (int gen = 0; gen < G; gen++) {
                 const Counters& c = per_gen[(size_t)gen];
-                const double steps = (double)std::max(1ull, c.section[0]), waves = (double)std::max(1ull, c.waves);
-                fprintf(stderr, "[rtx] gen %d: %llu rays, %llu steps in %llu waves (%.0f ticks each), %llu service passes (%.0f ticks each); "
-                        "mean wave lifetime %.1f us at 2.4 GHz: stepping %.1f, servicing %.1f\n", gen, c.rays, c.section[0], c.waves,
-                        (double)c.clk_traverse / steps, c.service_passes, (double)c.clk_service / std::max(1ull, c.service_passes),
-                        (double)c.clk_total / waves / 2400.0, (double)c.clk_traverse / waves / 2400.0, (double)c.clk_service / waves / 2400.0);
-                fprintf(stderr, "[rtx]        ticks per step: top of loop %.0f, request + fetch %.0f, the rest (processing) %.0f; fetching lanes per step %.1f\n",
-                        (double)c.clk_pop / steps, (double)c.clk_fetch / steps, ((double)c.clk_traverse - (double)c.clk_fetch) / steps, c.section[7] / steps);
-                fprintf(stderr, "[rtx]        lanes per step: traversing %.1f, evaluating objects %.1f, walking the bitmap %.1f, finishing hits %.1f, "
-                        "finished %.1f, empty %.1f\n", c.section[1] / steps, c.section[2] / steps, c.section[3] / steps, c.section[4] / steps,
-                        c.section[5] / steps, c.section[6] / steps);
+                fprintf(stderr, "[rtx] gen %d: %llu rays, %llu wave-steps, %llu service passes; longest wave %.1f us "
+                        "(at 2.4 GHz): %llu steps, %llu service passes\n", gen, c.rays, c.inner_steps + c.leaf_steps,
+                        c.service_passes, (double)c.max_wave_ticks / 2400.0, c.max_wave_steps & 0xFFFFFFFFull, c.max_wave_steps >> 32);
+                fprintf(stderr, "[rtx]        longest ray: %llu steps, %s, local pixel %llu\n", c.longest_ray >> 32,
+                        (c.longest_ray & 0x80000000ull) ? "shadow" : "radiance", c.longest_ray & 0x7FFFFFFFull);
+                const double nst = (double)std::max(1ull, c.inner_steps + c.leaf_steps);
+                fprintf(stderr, "[rtx]        ticks per wave-step: %.0f (fetch %.0f, pop %.0f); per service pass: %.0f; "
+                        "mean wave lifetime %.1f us (traversing %.1f, servicing %.1f)\n",
+                        (double)c.clk_traverse / nst, (double)c.clk_fetch / nst, (double)c.clk_pop / nst,
+                        (double)c.clk_service / std::max(1ull, c.service_passes),
+                        (double)c.clk_total / std::max(1ull, c.waves) / 2400.0, (double)c.clk_traverse / std::max(1ull, c.waves) / 2400.0,
+                        (double)c.clk_service / std::max(1ull, c.waves) / 2400.0);
+                fprintf(stderr, "[rtx]        rays by steps (<16 <32 <64 <128 <256 <512 <1024 more): %llu %llu %llu %llu %llu %llu %llu %llu\n",
+                        c.ray_steps_hist[0], c.ray_steps_hist[1], c.ray_steps_hist[2], c.ray_steps_hist[3], c.ray_steps_hist[4],
+                        c.ray_steps_hist[5], c.ray_steps_hist[6], c.ray_steps_hist[7]);
+                fprintf(stderr, "[rtx]        of which shadow rays: %llu %llu %llu %llu %llu %llu %llu %llu\n",
+                        c.shadow_steps_hist[0], c.shadow_steps_hist[1], c.shadow_steps_hist[2], c.shadow_steps_hist[3],
+                        c.shadow_steps_hist[4], c.shadow_steps_hist[5], c.shadow_steps_hist[6], c.shadow_steps_hist[7]);
             }
+    }
+    if (sc->counters_on && getenv("RTX_AMD_GEN_TIMING"))
+        fprintf(stderr, "[rtx] trace waves %llu: ticks/wave total %.0f traverse %.0f service %.0f; service passes %llu "
+                "(%.0f ticks each), traversal steps %llu (%.0f ticks each; fetch %.0f, pop %.0f)\n", ctr.waves,
+                (double)ctr.clk_total / std::max(1ull, ctr.waves), (double)ctr.clk_traverse / std::max(1ull, ctr.waves),
+                (double)ctr.clk_service / std::max(1ull, ctr.waves), ctr.service_passes,
+                (double)ctr.clk_service / std::max(1ull, ctr.service_passes), ctr.inner_steps + ctr.leaf_steps,
+                (double)ctr.clk_traverse / std::max(1ull, ctr.inner_steps + ctr.leaf_steps),
+                (double)ctr.clk_fetch / std::max(1ull, ctr.inner_steps + ctr.leaf_steps),
+                (double)ctr.clk_pop / std::max(1ull, ctr.inner_steps + ctr.leaf_steps));
+    if (sc->counters_on && getenv("RTX_AMD_GEN_TIMING")) {
+        static const char* names[4] = {"begin", "finalize", "next-job", "complete"};
+        for (int k = 0; k < 4; k++)
+            fprintf(stderr, "[rtx]   service %-9s %10llu lane-calls, %8.0f ticks each\n", names[k], ctr.section[4 + k],
+                    (double)ctr.section[k] / std::max(1ull, ctr.section[4 + k]));
     }
     if (stats) {
         if (sc->counters_on) {

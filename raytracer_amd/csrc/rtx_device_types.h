@@ -119,14 +119,12 @@ struct Scene {
     const FreeTri* ftris;
     const Mesh* meshes;
     const Inst* insts;
-    const Obj* objs;          // n_meshes + n_insts records (they live in the allocation below)
-    // Records: all Node4 records, then all Tri records, then all Obj records, in one allocation.
-    // A record is named by its offset in 128-byte units ("key"): node i has key 2i, triangle j
-    // has key tri_key0 + j, object k has key obj_key0 + 4k (its second half: + 2).  Child refs
-    // in Node4 and root refs in Obj are keys.  One base pointer and one shift turn any of them
-    // into an address, whatever the record kind: the cooperative fetch needs no per-kind branch.
+    const Obj* objs;          // n_meshes + n_insts records
+    // BLAS records: all Node4 records, then all Tri records, in one allocation.  A record is
+    // named by its offset in 128-byte units ("key"): node i has key 2i, triangle j has key
+    // tri_key0 + j.  Child refs in Node4 and root refs in Obj are keys.
     const char* blas;
-    int32_t tri_key0, obj_key0;
+    int32_t tri_key0, pad_blas;
     const double* tri_vn;     // RTX_VN_STRIDE per triangle (vertex normals of its corners) or null
     // TLAS: Node4 records among the BLAS records (a slot with cnt == -2 is instance `ref`);
     // box of everything and key of the root record
@@ -217,9 +215,6 @@ struct Launch {
     uint32_t wide_old;
     // Largest number of rays a wave of the trace kernel claims at once.
     uint32_t chunk_max, pad_launch;
-    // Lanes that must be waiting for a kind of work before the trace kernel runs it: box tests of
-    // nodes, triangle tests of leaves, object evaluations, hit finishing.
-    uint32_t quorum[4];
 };
 
 struct Counters {

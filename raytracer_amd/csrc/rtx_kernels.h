@@ -17,9 +17,16 @@
 // rays with one atomic add (lane 0) + readfirstlane broadcast; children are appended with a
 // ballot-compacted reservation (one atomic per wave per child slot), so queues stay dense.
 //
-// This file holds the arithmetic (box, triangle, plane, sphere tests), the cooperative record
-// fetch, the wave-wide traversal of a single job, the queues, and the shading and resolve
-// kernels; the closest-hit kernel itself is in rtx_trace.h.
+// Traversal is wave-cooperative.  Each lane walks its own ray through the BVH with its own
+// stack, but the 256-byte records the lanes need (a four-wide collapsed node, or two 128-byte
+// triangle records of a leaf) are fetched by the whole wave: sixteen lanes read one record as
+// sixteen adjacent 16-byte pieces, so one load instruction touches 4 records x 256 contiguous
+// bytes instead of 64 scattered 16-byte pieces.  The loads are LDS-DMA (global_load_lds_dwordx4):
+// the pieces land directly in the owner lane's 256-byte LDS row without passing through
+// registers.  Inner-node lanes and leaf lanes advance in the same step (both kinds of record
+// come through the same fetch), which keeps each lane's own visit order untouched.  Lanes are
+// refilled dynamically: a lane that finishes its ray (or the current object of its ray) picks
+// up its next job while the other lanes keep traversing (see "Per-lane ray state" below).
 //
 // All geometry arithmetic is FP64 in the reference's operation order and this file must be
 // compiled with -ffp-contract=off: primary-hit identity has to match the reference bit for
@@ -199,38 +206,37 @@ typedef __attribute__((address_space(3))) v2d lds_v2d;
 typedef __attribute__((address_space(1))) v4i glob_v4i;
 
 // Per-wave context: this wave's 64 LDS rows and the lane number.
-typedef __attribute__((address_space(3))) int lds_int;
-typedef __attribute__((address_space(3))) v4i lds_v4i;
-// keys: 64 dwords of LDS per wave through which the lanes learn the keys of the owners they serve
-struct Wave { lds_double* rows; lds_int* keys; unsigned lane; };
+struct Wave { lds_double* rows; unsigned lane; };
 
 // Wave-cooperative gather of one 256-byte record per requesting lane into that lane's LDS row.
-// `key` names the record by its offset in 128-byte units from `blas` (-1 = no request; the
-// lane's row then keeps what it holds): a collapsed node, a pair of triangle records, half an
-// object record.
+// `key` names the record by its offset in 128-byte
+// units from `blas` (-1 = no request): a collapsed node, or a pair of triangle records.
 //
 // Sixteen lanes read one record as sixteen adjacent 16-byte pieces, so one load instruction
 // touches 4 records x 256 contiguous bytes instead of 64 scattered pieces.  The loads are
 // LDS-DMA (global_load_lds_dwordx4, destination = wave-uniform base + 16*lane): in round g
 // lane l serves owner 4g + l/16, and the round fills the rows of owners 4g..4g+3.  The lanes
-// learn their owners' keys through 64 dwords of LDS (Wave::keys): owner w stores its key at
+// learn their owners' keys through the (still unused) row memory: owner w stores its key at
 // dword (w & 3)*16 + (w >> 2), so the sixteen keys a lane needs are 64 contiguous bytes.
 // To keep the owners' later 16-byte row reads free of bank conflicts the pieces are stored
 // XOR-swizzled: slot s of owner w holds piece s ^ (w & 15) -- applied to the *source* address
 // here and to the slot index in row_read.  Must be executed by every lane of the wave.
+typedef __attribute__((address_space(3))) int lds_int;
+typedef __attribute__((address_space(3))) v4i lds_v4i;
 RTX_DEV void coop_fetch(const Wave& wv, int key, const char* __restrict__ blas) {
     const unsigned lane = wv.lane, quarter = lane >> 4, slot = lane & 15u;
-    wv.keys[(lane & 3u) * 16u + (lane >> 2)] = key;
+    ((lds_int*)wv.rows)[(lane & 3u) * 16u + (lane >> 2)] = key;
     __builtin_amdgcn_wave_barrier();
     int okeys[16];
     {
-        const lds_v4i* kp = (const lds_v4i*)wv.keys + quarter * 4u;
+        const lds_v4i* kp = (const lds_v4i*)wv.rows + quarter * 4u;
 #pragma unroll
         for (int q = 0; q < 4; q++) {
             const v4i v = kp[q];
             okeys[4 * q] = v.x; okeys[4 * q + 1] = v.y; okeys[4 * q + 2] = v.z; okeys[4 * q + 3] = v.w;
         }
     }
+    // the keys must have left the row memory before the first record lands in it
     __builtin_amdgcn_s_waitcnt(0xC07F);          // lgkmcnt(0); vmcnt and expcnt left at "no wait"
     __builtin_amdgcn_wave_barrier();
     // Source address of this lane's piece in round g: piece = slot ^ ((4g + quarter) & 15)
@@ -397,6 +403,31 @@ RTX_DEV void free_tri_hit(const Scene& S, V3 ro, V3 rd, int index, double& t_min
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// Per-lane ray state of the trace kernel.
+//
+// A lane owns one ray at a time and walks it through the reference's object sequence
+// (utils.cpp:671-865): planes -> free triangles -> meshes (in index order) -> spheres ->
+// instances (in index order).  Meshes and instances are *traversal jobs*: (mesh, object-space
+// ray, bound).  The wave runs all its lanes' jobs together in one cooperative traversal
+// loop; a lane whose job ends waits until enough lanes need service, then the wave runs one
+// divergent "service pass" that finishes jobs, selects each lane's next job, retires
+// completed rays and claims fresh rays for idle lanes.  This keeps the lanes of a wave busy
+// although rays differ wildly in length.
+//
+// Only what a traversal step touches lives in registers.  The Intersection record
+// (scene.h:248-264) lives in HBM, in the ray's slot of the hit buffer: the few events that
+// write it (an accepted hit, or the half-written record of utils.cpp:567-570 / 719-721)
+// store exactly the fields the reference writes at that point, so the slot always holds
+// what the reference's `intersection` holds; registers keep only the bound, the record's
+// distance and the hit flag.
+// ---------------------------------------------------------------------------------------
+enum { LS_EMPTY = 0, LS_NEED_JOB = 1, LS_JOB_DONE = 2, LS_IN_JOB = 3 };
+
+#ifndef RTX_SERVICE_THRESHOLD
+#define RTX_SERVICE_THRESHOLD 24     // lanes waiting for service that trigger a service pass ...
+#endif
+#define RTX_SERVICE_THRESHOLD_INSTANCED 36   // ... and in scenes where a pass replays many instance candidates
 #ifndef RTX_SERVICE_REPS
 #define RTX_SERVICE_REPS 4           // rounds of a service pass: lanes whose ray ended in one round are refilled in the next
 #endif
@@ -412,8 +443,11 @@ RTX_DEV void free_tri_hit(const Scene& S, V3 ro, V3 rd, int index, double& t_min
 #ifndef RTX_SCATTER_SHIFT_THIN
 #define RTX_SCATTER_SHIFT_THIN 0           // log2 of their group size
 #endif
+#ifndef RTX_REPLAY_CAP
+#define RTX_REPLAY_CAP 3             // instance candidates a lane may turn down per service visit before it yields (instance-heavy scenes)
+#endif
 #ifndef RTX_LDS_OBJS
-#define RTX_LDS_OBJS 10              // object records (512 B each) kept in LDS per block: the first so many of the scene
+#define RTX_LDS_OBJS 12              // object records (512 B each) kept in LDS per block: the first so many of the scene
 #endif
 #ifndef RTX_SCATTER0_SHIFT
 #define RTX_SCATTER0_SHIFT 6         // generation 0: whole 8x8 pixel blocks (64 items) are scattered
@@ -428,6 +462,30 @@ RTX_DEV void free_tri_hit(const Scene& S, V3 ro, V3 rd, int index, double& t_min
 #ifndef RTX_TRACE_WAVES
 #define RTX_TRACE_WAVES 2            // waves per SIMD the trace kernel is compiled for (2: 256 VGPRs)
 #endif
+
+struct Lane {
+    V3 o, d;                // world-space ray
+    double t_min, dist;     // current bound; Intersection::distance of the record
+    unsigned slot;          // queue slot (work item for generation 0) = hit-record slot
+    int is_shadow, hit;
+    // object iterator: it <= n_meshes: meshes (job = object it-1); it > n_meshes: instances, taken in
+    // ascending index from the lane's two-level instance bitmap: bitmap word `word` is being
+    // consumed (`bits` = its remaining candidates); which words hold any is recorded in summary
+    // words, of which `sword` is being consumed (`sbits`) and `whi` is the last that has any.
+    // While the TLAS walk runs, word/whi are the lowest/highest bitmap word it has marked.
+    int it, word, whi, sword;
+    unsigned bits, sbits;
+    // current traversal job
+    int obj;
+    double orig_t_min;
+    V3 ro, rd;
+    double ix, iy, iz;
+    int par;
+    int cur_ref, cur_cnt, sp, btri;
+    int state;
+    int age;                // traversal steps spent on the current job (with counters on: on the current ray)
+    v4i top;                // top stack entry (valid while sp > 0)
+};
 
 // Where a lane's record goes.  Shadow rays need only (hit, distance), which stay in registers.
 struct RecOut {
@@ -448,13 +506,296 @@ struct RecOut {
     RTX_DEV void src(int s) const { if (on && ids) rec->src = s; }
 };
 
-// Per-block LDS data of the trace kernel: the scene's first n object records, and per lane five
-// doubles (ctx) for what a shadow ray needs again after its traversal.
+// A fresh ray: empty record, then the classes that come before the meshes
+// (planes, utils.cpp:683-685; free triangles, utils.cpp:692-729).
+// The scene's first object records, copied to LDS when the block starts.  A lane that moves on
+// to its next object reads the record in a chain of dependent loads (flags and boxes, then the
+// matrix, then the root); from LDS each link costs a fraction of a trip to L2.  Records beyond
+// the cached ones are read from memory (one pointer type serves both).
+// ctx: five doubles of LDS per lane for what a shadow ray needs again after its traversal --
+// its light's distance (at every change of object) and, if it ends unoccluded, pixel and
+// weight -- taken from the ray record together with origin and direction, in the same trip.
 struct ObjCache {
     const Obj* lds;
     int n;
     double* ctx;          // [0] light distance, [1..3] weight, [4] pixel (low word)
+    RTX_DEV const Obj* at(const Scene& S, int oi) const { return oi < n ? lds + oi : S.objs + oi; }
 };
+
+template <bool COUNT>
+RTX_DEV void ray_begin(const Scene& S, Lane& L, const RecOut& out, const double bound0, Tally& tl) {
+    L.t_min = bound0;                 // DBL_MAX in the reference (utils.cpp:676)
+    L.dist = 0.0;
+    L.hit = 0;
+    if (S.n_planes > 0 || S.n_ftris > 0) {
+        Rec r;
+        r.hit = 0; r.dist = 0.0; r.beta = 0.0; r.gamma = 0.0;
+        r.point = mk(0, 0, 0); r.gn = mk(0, 0, 0); r.sn = mk(0, 0, 0);
+        r.kind = RTX_KIND_NONE; r.container = -1; r.face = -1; r.tri = -1; r.mat = -1; r.src = -1;
+        bool hit = false;
+        for (int i = 0; i < S.n_planes; i++) hit = plane_hit(S, L.o, L.d, i, L.t_min, r) || hit;
+        for (int i = 0; i < S.n_ftris; i++) free_tri_hit<COUNT>(S, L.o, L.d, i, L.t_min, r, hit, tl);
+        if (r.hit) {
+            out.geom(r.dist, r.point, r.gn, r.sn);
+            out.bary(r.beta, r.gamma, r.face, r.tri);
+            out.owner(r.mat, r.container);
+            out.kind(r.kind);
+            out.src(r.src);
+            L.dist = r.dist;
+        }
+        L.hit = hit ? 1 : 0;
+    }
+    L.it = 0; L.word = 0; L.whi = -1; L.bits = 0u; L.sword = 0; L.sbits = 0u; L.age = 0;
+    L.state = LS_NEED_JOB;
+}
+
+// Advance the lane's object iterator until an object needs traversal (returns 1, job set
+// up: rayHitsMesh's prologue, utils.cpp:418-494 + the root test of bvh.cpp:132), the object
+// sequence is exhausted (returns 0), or the lane has turned down CAP instance candidates in
+// this call (returns 2: call again in the next service pass).
+template <bool COUNT, bool FAST, int CAP>
+RTX_DEV int job_next(const Scene& S, const ObjCache& oc, Lane& L, const RecOut& out, unsigned* inst_bits, const double light_dist, Tally& tl) {
+    const unsigned n_summary = rtx_summary_words(S.n_insts);
+    const Slab ws = make_slab(L.o, L.d);         // world-space slab constants, once per call
+    int turned_down = 0;
+    while (true) {
+        // A service pass lasts as long as its slowest lane.  A lane that keeps turning instance
+        // candidates down (each a chain of dependent loads) yields after CAP of them and goes on in
+        // the next pass, instead of holding up the lanes that already have their jobs (CAP = 0: no
+        // limit; the variant for scenes with few instances has none).
+        if (CAP > 0 && L.it > S.n_meshes && turned_down++ >= CAP) return 2;
+        int oi;
+        if (L.it < S.n_meshes) {                                     // utils.cpp:736-739
+            oi = L.it; L.it++;
+        } else {
+            if (L.it == S.n_meshes) {                                // utils.cpp:746-748
+                L.it++;
+                if (S.n_spheres > 0) {
+                    Rec r;
+                    r.kind = -1; r.dist = 0.0; r.hit = 0; r.mat = -1; r.container = -1; r.src = -1;
+                    r.point = mk(0, 0, 0); r.gn = r.point; r.sn = r.point;
+                    bool hit = L.hit != 0;
+                    for (int i = 0; i < S.n_spheres; i++) hit = sphere_hit(S, L.o, L.d, i, L.t_min, r) || hit;
+                    if (r.kind != -1) {                              // fields a sphere hit writes, utils.cpp:269-291
+                        out.geom(r.dist, r.point, r.gn, r.sn);
+                        out.owner(r.mat, r.container);
+                        out.kind(r.kind);
+                        out.src(r.src);
+                        L.dist = r.dist;
+                    }
+                    L.hit = hit ? 1 : 0;
+                }
+                // Instances (utils.cpp:756-790).  A walk of the TLAS -- a traversal job like a
+                // mesh's, run by the cooperative loop with the world-space ray -- marks the
+                // candidates in the lane's bitmap: instances whose world box the ray can meet
+                // within the current bound (a box missed now stays missed because the bound
+                // never grows).  They are then replayed in ascending index through the
+                // reference's own per-instance logic (world-box test against the then-current
+                // bound included).
+                L.word = INT_MAX; L.whi = -1; L.bits = 0u; L.sbits = 0u; L.sword = -1;
+                if (S.n_insts > 0 && S.n_insts <= RTX_LINEAR_INSTS) {
+                    // a handful of instances: every one is a candidate (the reference's own loop,
+                    // utils.cpp:756-790); a TLAS walk would cost more than it can save
+                    L.word = 0; L.bits = (1u << S.n_insts) - 1u; L.sword = 0; L.whi = 0;
+                } else if (S.n_insts > 0) {
+                    double tl_min[3] = {S.tl_min[0], S.tl_min[1], S.tl_min[2]}, tl_max[3] = {S.tl_max[0], S.tl_max[1], S.tl_max[2]};
+                    double enter;
+                    if (box_enter(tl_min, tl_max, ws, enter) && (L.t_min >= enter)) {
+                        L.obj = -1;                                  // marks the job as the TLAS walk
+                        L.is_shadow &= 1;
+                        if (!COUNT) L.age = 0;
+                        L.orig_t_min = L.t_min;
+                        L.ro = L.o; L.rd = L.d; L.ix = ws.ix; L.iy = ws.iy; L.iz = ws.iz; L.par = ws.par;
+                        L.cur_ref = S.tl_key; L.cur_cnt = 0; L.sp = 0; L.btri = -1;
+                        return 1;
+                    }
+                }
+            }
+            while (L.bits == 0u) {
+                while (L.sbits == 0u) {
+                    if (L.sword >= L.whi) return 0;
+                    L.sword++;
+                    L.sbits = atomicExch(inst_bits + L.sword, 0u);           // summary words come first in the lane's area
+                }
+                L.word = L.sword * 32 + (__ffs((int)L.sbits) - 1);
+                L.sbits &= L.sbits - 1u;
+                L.bits = atomicExch(inst_bits + n_summary + L.word, 0u);     // take the word's candidates, leave it clear
+            }
+            const int idx = L.word * 32 + (__ffs((int)L.bits) - 1);
+            L.bits &= L.bits - 1u;
+            oi = S.n_meshes + idx;
+        }
+        // second 128 bytes of the object record in one batch: world box, root box, root, flags
+        const Obj* ob = oc.at(S, oi);
+        double ob2[16];
+        {
+            const v2d* p2 = (const v2d*)ob->bmin;
+#pragma unroll
+            for (int k = 0; k < 7; k++) { const v2d v = p2[k]; ob2[2 * k] = v.x; ob2[2 * k + 1] = v.y; }
+        }
+        // While that record is on its way: if this was its bitmap word's last candidate, take the next
+        // word (or the next summary word) now, in the same trip, instead of in a trip of its own later.
+        if (oi >= S.n_meshes && L.bits == 0u) {
+            if (L.sbits != 0u) {
+                L.word = L.sword * 32 + (__ffs((int)L.sbits) - 1);
+                L.sbits &= L.sbits - 1u;
+                L.bits = atomicExch(inst_bits + n_summary + L.word, 0u);
+            } else if (L.sword < L.whi) {
+                L.sword++;
+                L.sbits = atomicExch(inst_bits + L.sword, 0u);
+            }
+        }
+        const int root_ref = __double2loint(ob2[12]), root_count = __double2hiint(ob2[12]);
+        const int flags = __double2loint(ob2[13]);
+        if (flags & OBJ_SKIP) continue;
+        V3 ro = L.o, rd = L.d;
+        double bound = L.t_min;
+        if (flags & OBJ_XF) {
+            if (flags & OBJ_BOUNDS) {                                // utils.cpp:446-466, 760-766
+                if (COUNT) tl.world_box++;
+                double enter;
+                if (!box_enter(ob2 + 0, ob2 + 3, ws, enter) || !(L.t_min >= enter)) continue;
+            }
+            if (COUNT) tl.obj_trav++;
+            double inv[16];
+            {
+                const v2d* p1 = (const v2d*)ob->inv;
+#pragma unroll
+                for (int k = 0; k < 8; k++) { const v2d v = p1[k]; inv[2 * k] = v.x; inv[2 * k + 1] = v.y; }
+            }
+            ro = xf_point(inv, L.o);                                 // utils.cpp:481-489
+            rd = normalize_f32(xf_dir(inv, L.d));
+            if (FAST) {
+                // consistent mode: the bound goes to object space with the ray (the divisor is the
+                // factor normalize_f32 applied to the direction)
+                const V3 od = xf_dir(inv, L.d);
+                bound = L.t_min / (1.0 / (double)sqrtf((float)(od.x * od.x + od.y * od.y + od.z * od.z)));
+            }
+        }
+        // (an untransformed object is met by the world-space ray: same constants, no second set of divisions)
+        const Slab sl = (flags & OBJ_XF) ? make_slab(ro, rd) : ws;
+        double enter;
+        if (!box_enter(ob2 + 6, ob2 + 9, sl, enter) || !(bound >= enter)) continue;
+        L.obj = oi;
+        L.orig_t_min = L.t_min;
+        if (FAST) L.t_min = bound;
+        L.is_shadow &= 1;
+        if (!COUNT) L.age = 0;       // (steps of the job; with counters on: of the ray, for the histogram)
+        if (FAST && L.is_shadow) {
+            // consistent mode: a shadow ray's bound starts at the light's distance, so the first
+            // accepted triangle of any job, transformed or not, decides it
+            L.is_shadow = 3;
+            L.orig_t_min = bound;
+        } else if (!COUNT && L.is_shadow && !(flags & OBJ_XF)) {
+            // A shadow ray asks only whether something lies in front of the light
+            // (utils.cpp:1066-1084: hit && distance < |L - P|).  Once a hit has been accepted
+            // with the bound below that distance the answer is yes whatever follows: the bound
+            // never grows, every later write to the record's distance is below the bound of
+            // its moment, and the hit flag is never taken back.  In an untransformed mesh an
+            // accepted triangle is such a hit, so the job may stop there (bit 1 of is_shadow;
+            // orig_t_min, unused by untransformed jobs, carries the light's distance).
+            // Transformed jobs decide acceptance only at their end (utils.cpp:559-570).
+            // With counters on every test of the reference is carried out.
+            L.is_shadow = 3;
+            L.orig_t_min = light_dist;
+        }
+        L.ro = ro; L.rd = rd; L.ix = sl.ix; L.iy = sl.iy; L.iz = sl.iz; L.par = sl.par;
+        L.cur_ref = root_ref; L.cur_cnt = root_count; L.sp = 0; L.btri = -1;
+        return 1;
+    }
+}
+
+// End of a traversal job: what rayHitsMesh does after bvh->traverse returns
+// (utils.cpp:533-668), including the fields the winning triangle test wrote
+// (utils.cpp:370-381, bvh.cpp:162).  beta and gamma of the winning triangle are recomputed
+// here with the same arithmetic that accepted it (same inputs, same bits).
+template <bool FAST>
+RTX_DEV void job_finalize(const Scene& S, const ObjCache& oc, Lane& L, const RecOut& out) {
+    if (L.btri < 0) {
+        if (FAST) L.t_min = L.orig_t_min;         // (a transformed job ran with the object-space bound)
+        return;
+    }
+    const int tri = L.btri - S.tri_key0;             // triangle index (the traversal works with record keys)
+    const RTX_GLOBAL Tri* Tg = (const RTX_GLOBAL Tri*)(S.blas + (size_t)(unsigned)L.btri * 128u);
+    const Obj* ob = oc.at(S, L.obj);
+    if (!out.on && !(ob->flags & OBJ_XF)) {
+        // a shadow ray keeps no record: of an untransformed hit only distance and flag remain
+        L.dist = L.t_min; L.hit = 1;
+        return;
+    }
+    double T[9];
+#pragma unroll
+    for (int k = 0; k < 3; k++) { T[k] = Tg->a[k]; T[3 + k] = Tg->e1[k]; T[6 + k] = Tg->e2[k]; }
+    const int face = Tg->face;
+    const V3 gn = mk(Tg->gn[0], Tg->gn[1], Tg->gn[2]);
+    const int flags = ob->flags, mat = ob->material, mi = ob->mesh;
+    double t, beta, gamma;
+    tri_test(T, L.ro, L.rd, INFINITY, S.isect_eps, t, beta, gamma);
+    const V3 a = mk(T[0], T[1], T[2]), e1 = mk(T[3], T[4], T[5]), e2 = mk(T[6], T[7], T[8]);
+    const V3 point = vadd(vadd(a, sscale(beta, e1)), sscale(gamma, e2));
+    if (!FAST) {
+        out.bary(beta, gamma, face, tri);
+        out.kind(RTX_KIND_MESH);
+    }
+    if (!(flags & OBJ_XF)) {
+        if (FAST) { out.bary(beta, gamma, face, tri); out.kind(RTX_KIND_MESH); }
+        out.geom(L.t_min, point, gn, gn);
+        out.owner(mat, mi);
+        out.src(L.obj);
+        L.dist = L.t_min; L.hit = 1;
+        return;
+    }
+    double m[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) m[k] = ob->m[k];
+    V3 wp = xf_point(m, point);
+    double dx = wp.x - L.o.x, dy = wp.y - L.o.y, dz = wp.z - L.o.z;
+    double wd = (double)sqrtf((float)(dx * dx + dy * dy + dz * dz));
+    if (FAST) {
+        // consistent mode: a hit that is not nearer than the bound leaves no trace
+        if (wd >= L.orig_t_min) { L.t_min = L.orig_t_min; return; }
+        out.bary(beta, gamma, face, tri);
+        out.kind(RTX_KIND_MESH);
+    }
+    if (wd >= L.orig_t_min) {             // utils.cpp:567-570: bound restored, record is not
+        out.geom(L.t_min, point, gn, gn);
+        out.owner(mat, mi);
+        L.dist = L.t_min;
+        L.t_min = L.orig_t_min;
+        return;
+    }
+    if (!out.on) { L.dist = wd; L.t_min = wd; L.hit = 1; return; }      // (shadow ray: no record)
+    double nrm[12];
+#pragma unroll
+    for (int k = 0; k < 12; k++) nrm[k] = ob->nrm[k];
+    V3 wg = normalize_f32(xf_dir(nrm, gn));
+    V3 ws;
+    if (flags & OBJ_SMOOTH_VN) {          // utils.cpp:589-621
+        double u = beta, v = gamma, w = 1.0 - u - v;
+        const RTX_GLOBAL double* vn = (const RTX_GLOBAL double*)S.tri_vn + RTX_VN_STRIDE * (size_t)tri;
+        double nx = w * vn[0] + u * vn[3] + v * vn[6];
+        double ny = w * vn[1] + u * vn[4] + v * vn[7];
+        double nz = w * vn[2] + u * vn[5] + v * vn[8];
+        double nlen = (double)sqrtf((float)(nx * nx + ny * ny + nz * nz));
+        double ninv = 1.0 / nlen;
+        nx *= ninv; ny *= ninv; nz *= ninv;
+        ws = xf_dir(nrm, mk(nx, ny, nz));
+    } else {
+        ws = xf_dir(nrm, gn);
+    }
+    {
+        double slen = (double)sqrtf((float)(ws.x * ws.x + ws.y * ws.y + ws.z * ws.z));
+        double sinv = 1.0 / slen;
+        ws.x *= sinv; ws.y *= sinv; ws.z *= sinv;
+    }
+    if (dot(wg, L.d) > 0.0) { wg = vneg(wg); ws = vneg(ws); }
+    out.geom(wd, wp, wg, ws);
+    out.owner(mat, -2);
+    out.src(L.obj);
+    L.dist = wd;
+    L.t_min = wd;
+    L.hit = 1;
+}
 
 // utils.cpp:1089-1111
 RTX_DEV double fresnel_conductor(double cosTheta, double n, double k) {
@@ -610,6 +951,135 @@ RTX_DEV V3 primary_direction(const Frame& F, int px, int py) {
     return normalize(vsub(s, e));
 }
 
+// Divergent per-lane part of a service pass.  `fresh`: the lane has just been handed a new ray
+// (L.slot / L.o / L.d / L.is_shadow set).
+template <bool COUNT, bool FAST, int CAP>
+RTX_DEV void service_lane(const Launch* __restrict__ Lp, const ObjCache& oc, const int gen, double* __restrict__ accum,
+                          rtx_hit_id* __restrict__ aov, Lane& L, unsigned* inst_bits, const bool fresh, Tally& tl) {
+    const Scene& S = Lp->S;
+    const Frame& F = Lp->F;
+    const Queue& qin = Lp->q[(gen + 1) & 1];
+    const unsigned slot = L.slot;
+    RecOut out;
+    out.rec = (RTX_GLOBAL Hit*)Lp->hb.recs + slot; out.on = L.is_shadow == 0; out.ids = (gen == 0 && aov != nullptr);
+    long long c0 = COUNT ? clock64() : 0;
+    if (fresh) {
+        if (COUNT) { tl.rays++; if (gen == 0) tl.primary++; else if (L.is_shadow) tl.shadow++; else tl.secondary++; }
+        // consistent mode: a shadow ray looks no further than its light
+        ray_begin<COUNT>(S, L, out, FAST && L.is_shadow ? oc.ctx[0] : DBL_MAX, tl);
+        if (COUNT) { const long long c = clock64(); tl.sec[0] += (unsigned long long)(c - c0); tl.sec[4]++; c0 = c; }
+    }
+    if (L.state == LS_JOB_DONE) {
+        if (L.obj == -1) {
+            // end of the TLAS walk: L.word .. L.whi is the range of bitmap words it marked;
+            // consumption starts in front of the first summary word that covers them
+            L.sword = L.word == INT_MAX ? -1 : (L.word >> 5) - 1;
+            L.whi = L.whi < 0 ? -1 : (L.whi >> 5);
+            L.bits = 0u; L.sbits = 0u;
+            L.obj = -2;
+        } else if (FAST && L.is_shadow) {
+            // consistent mode: any accepted triangle occludes; the bound is the light's distance again
+            if (L.btri >= 0) L.hit = 1;
+            L.t_min = oc.ctx[0];
+        } else {
+            job_finalize<FAST>(S, oc, L, out);
+        }
+        L.state = LS_NEED_JOB;
+        if (COUNT) { const long long c = clock64(); tl.sec[1] += (unsigned long long)(c - c0); tl.sec[5]++; c0 = c; }
+    }
+    // A shadow ray with an accepted hit in front of its light is decided (see job_next) and is
+    // retired here.  Instance candidates it has collected but not replayed are dropped: the
+    // lane's candidate bitmap must be clear when the next ray starts.
+    double light_dist = 0.0;
+    if (!COUNT && L.is_shadow) light_dist = oc.ctx[0];
+    const bool decided = !COUNT && L.is_shadow && L.hit != 0 && (FAST || L.t_min < light_dist);
+    if (decided && L.it > S.n_meshes) {
+        // (the current word was cleared when it was taken; what is still set in memory: the
+        // words flagged in the current summary word, and the summary words not yet taken)
+        const unsigned n_summary = rtx_summary_words(S.n_insts);
+        unsigned sb = L.sbits;
+        int sw = L.sword;
+        while (true) {
+            while (sb != 0u) {
+                const int w = sw * 32 + (__ffs((int)sb) - 1);
+                sb &= sb - 1u;
+                __hip_atomic_store(inst_bits + n_summary + w, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (sw >= L.whi) break;
+            sw++;
+            sb = atomicExch(inst_bits + sw, 0u);
+        }
+        L.bits = 0u; L.sbits = 0u; L.sword = L.whi;
+    }
+    const int more = decided ? 0 : job_next<COUNT, FAST, CAP>(S, oc, L, out, inst_bits, light_dist, tl);
+    if (COUNT) { const long long c = clock64(); tl.sec[2] += (unsigned long long)(c - c0); tl.sec[6]++; c0 = c; }
+    if (more == 1) { L.state = LS_IN_JOB; return; }
+    if (more == 2) { L.state = LS_NEED_JOB; return; }          // yielded: more candidates next time
+    // ---- ray complete ------------------------------------------------------------------------
+    const bool hit = L.hit != 0;
+    if (L.is_shadow) {                                            // utils.cpp:1083
+        if (!(hit && (FAST || L.dist < oc.ctx[0])))
+            add_color(accum, (unsigned)__double2loint(oc.ctx[4]), mk(oc.ctx[1], oc.ctx[2], oc.ctx[3]));
+    } else {
+        if (gen == 0 && aov != nullptr) {
+            int px, py; unsigned pixel;
+            primary_pixel(F, slot, px, py, pixel);
+            rtx_hit_id h;
+            h.kind = 0; h.container = -1; h.face = -1; h.src = -1; h.distance = 0.0;
+            if (hit) {
+                // read back what this lane stored (bypassing the vector L1)
+                Hit* rec = Lp->hb.recs + slot;
+                h.kind = __hip_atomic_load(&rec->kind, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                h.container = __hip_atomic_load(&rec->container, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const int face = __hip_atomic_load(&rec->face, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const int src = __hip_atomic_load(&rec->src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                h.face = (h.kind == RTX_KIND_MESH || h.kind == RTX_KIND_TRIANGLE) ? face : -1;
+                h.src = h.kind == RTX_KIND_MESH ? src : h.container;
+                h.distance = L.dist;
+            }
+            aov[(size_t)py * F.width + px] = h;
+        }
+        out.rec->code = hit ? 1 : -1;
+    }
+    L.state = LS_EMPTY;
+    if (COUNT) {
+        tl.sec[3] += (unsigned long long)(clock64() - c0); tl.sec[7]++;
+        // ray length histogram: < 16, < 32, ... < 1024, >= 1024 steps
+        int b = 0;
+        for (int a = L.age >> 4; a > 0 && b < 7; a >>= 1) b++;
+        tl.hist[b]++;
+        if (L.is_shadow) tl.hist_shadow[b]++;
+        unsigned pix = slot;
+        if (gen != 0) pix = ((const RTX_GLOBAL Ray*)qin.rays + slot)->pixel;
+        const unsigned long long packed = ((unsigned long long)(unsigned)L.age << 32) | (unsigned long long)(pix & 0x7FFFFFFFu) |
+                                          (L.is_shadow ? 0x80000000ull : 0ull);
+        if (packed > tl.longest_ray) tl.longest_ray = packed;
+    }
+}
+
+// The traversal loop: runs cooperative steps for the lanes that are inside a job until the
+// wave needs a service pass (enough lanes wait for one) or no lane is traversing.
+// `refillable`: idle lanes could be handed new rays, so they count as waiting for service.
+//
+// In one step every traversing lane advances by one 256-byte record: a lane at an inner node
+// gets the collapsed node (the boxes of up to four grandchildren) and descends two binary
+// levels, a lane in a leaf gets the leaf's next two triangles and tests them in order.  Both kinds of record arrive through the same cooperative fetch, so the step has
+// a single exposed memory latency whatever the mix of lanes.
+//
+// Visit order and visited set of bvh.cpp:104-185: children ordered near/far by the sign of
+// dir[splitAxis] (near first); a node is entered iff its box test passes with the bound current
+// when the reference would pop it.  A child's box is evaluated at its (grand)parent; children
+// that are not entered at once are pushed with their entry distance and re-checked against the
+// (possibly smaller) bound when popped -- the predicate the reference evaluates at that
+// moment.  Skipping the intermediate binary node's own test changes nothing: the slab
+// arithmetic is monotone, so a box that passes lies inside a parent box that passes too, and
+// the bound only shrinks between the parent's turn and the child's.
+//
+// Stack entries are 16 bytes (entry distance, ref, count) in a per-lane region of global
+// memory (private "scratch" arrays interleave lanes dword by dword, which makes a 16-byte
+// access at lane-varying depth touch four cache lines per lane).  The top entry is kept in
+// registers (Lane::top); memory holds the entries below it, so the load a pop issues to refill
+// the top is not needed before the next pop and overlaps the next record fetch.
 // One candidate child of a collapsed node while the visit order is being established.
 struct Cand { double e; int ref, cnt; bool ok; };
 RTX_DEV void cand_swap(Cand& a, Cand& b, bool doit) {
@@ -859,6 +1329,383 @@ __device__ __attribute__((noinline)) WideOut wide_job(const Scene& S, const Wave
     out.t_min = tmin; out.btri = trmin; out.wmin = all_wmin; out.wmax = all_wmax;
     __builtin_amdgcn_wave_barrier();
     return out;
+}
+
+// Run the jobs of the lanes in `m` wave-wide, one after the other.
+RTX_DEV void wide_jobs(const Scene& S, const Wave& wv, Lane& L, glob_v4i* stk, unsigned* inst_bits,
+                       unsigned long long m) {
+    WideIn in;
+    in.rox = L.ro.x; in.roy = L.ro.y; in.roz = L.ro.z; in.rdx = L.rd.x; in.rdy = L.rd.y; in.rdz = L.rd.z;
+    in.ix = L.ix; in.iy = L.iy; in.iz = L.iz; in.t_min = L.t_min; in.stop = L.orig_t_min;
+    in.par = L.par; in.shadow = L.is_shadow; in.sp = L.sp; in.cur_ref = L.cur_ref; in.cur_cnt = L.cur_cnt; in.top = L.top;
+    while (m != 0ull) {
+        const int src = __ffsll((long long)m) - 1;
+        m &= m - 1ull;
+        const WideOut out = wide_job(S, wv, in, stk, inst_bits, src);
+        if ((int)wv.lane == src) {
+            if (out.t_min < INFINITY) { L.t_min = out.t_min; L.btri = out.btri; }
+            L.word = min(L.word, out.wmin); L.whi = max(L.whi, out.wmax);
+            L.sp = 0;
+            L.state = LS_JOB_DONE;
+        }
+    }
+}
+
+template <bool COUNT, int WIDE>
+RTX_DEV unsigned long long traverse_steps(const Scene& S, const Wave& wv, Lane& L, glob_v4i* __restrict__ stk, unsigned* inst_bits,
+                            const int service_threshold, const bool refillable, const int wide_lanes, const int wide_age, Tally& tl) {
+    const unsigned lane = wv.lane;
+    const unsigned n_summary = rtx_summary_words(S.n_insts);
+    const char* const blas = S.blas;
+    const bool cull = S.cull != 0;
+    const double isect_eps = S.isect_eps;
+    Slab sl;
+    sl.ox = L.ro.x; sl.oy = L.ro.y; sl.oz = L.ro.z; sl.ix = L.ix; sl.iy = L.iy; sl.iz = L.iz; sl.par = L.par;
+
+    while (true) {
+        const bool in_job = L.state == LS_IN_JOB;
+        const bool at_leaf = in_job && L.cur_cnt > 0;
+        const unsigned long long m_job = __ballot(in_job);
+        if (m_job == 0ull) break;
+        const unsigned long long m_wait = __ballot(L.state == LS_NEED_JOB || L.state == LS_JOB_DONE ||
+                                                   (refillable && L.state == LS_EMPTY));
+        if (__popcll(m_wait) >= service_threshold) break;
+        // the generation has drained and this wave holds its last few jobs: the caller finishes them wave-wide
+        if (!COUNT && WIDE != 0 && !refillable && __popcll(m_job) <= wide_lanes) {
+            const unsigned long long m_old = WIDE == 2 ? m_job : __ballot(in_job && L.age >= wide_age);
+            if (m_old != 0ull) return m_old;
+        }
+        if (COUNT) {
+            const int nl = __popcll(__ballot(at_leaf)), nj = __popcll(m_job);
+            if (lane == 0) {
+                if (nj > nl) { tl.inner_steps++; tl.inner_lanes += (unsigned)(nj - nl); }
+                if (nl) { tl.leaf_steps++; tl.leaf_lanes += (unsigned)nl; }
+            }
+        }
+        // rays with an axis-parallel component are rare: the wave takes the general box test
+        // only when one of its traversing lanes has one
+        const bool any_par = __ballot(in_job && L.par != 0) != 0ull;
+
+        // The lane's 256-byte record: a collapsed node, or two consecutive triangle records.
+        // A wave with only a lane or two still traversing is on the frame's critical path (the
+        // longest rays of a generation); it loads the records directly, one memory round trip
+        // without the detour through LDS.  Otherwise the wave fetches cooperatively.
+        const long long f0 = COUNT ? clock64() : 0;
+        double rec[32];
+        if (__popcll(m_job) <= RTX_SPARSE_LANES) {
+            if (in_job) {
+                const RTX_GLOBAL v2d* gp = (const RTX_GLOBAL v2d*)(blas + ((size_t)(unsigned)L.cur_ref << 7));
+#pragma unroll
+                for (int p = 0; p < 16; p++) { const v2d v = gp[p]; rec[2 * p] = v.x; rec[2 * p + 1] = v.y; }
+            }
+        } else {
+            coop_fetch(wv, in_job ? L.cur_ref : -1, blas);
+            if (in_job) row_read<0, 16>(wv, rec);
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (COUNT) tl.clk_fetch += (unsigned long long)(clock64() - f0);
+
+        bool need_pop = false;
+        if (in_job) {
+            L.age++;
+            if (!at_leaf) {
+                // ---- collapsed inner node: up to four grandchildren of a binary node ------------
+                if (COUNT) { if (L.obj == -1) tl.tlas_visits++; else tl.node_visits++; }
+                const double* nd = rec;
+                Cand c[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    c[k].ref = k & 1 ? __double2hiint(nd[24 + (k >> 1)]) : __double2loint(nd[24 + (k >> 1)]);
+                    c[k].cnt = k & 1 ? __double2hiint(nd[26 + (k >> 1)]) : __double2loint(nd[26 + (k >> 1)]);
+                    double e;
+                    bool hit;
+                    if (any_par) hit = box_enter(nd + 6 * k, nd + 6 * k + 3, sl, e);
+                    else hit = box_enter_nopar(nd + 6 * k, nd + 6 * k + 3, sl, e);
+                    c[k].e = e;
+                    const bool pass = hit & (L.t_min >= e);
+                    c[k].ok = pass & (c[k].cnt >= 0);
+                    if (pass && c[k].cnt == -2) {
+                        // TLAS walk: the slot is a mesh instance whose world box the ray can meet
+                        const int w = c[k].ref >> 5;
+                        atomicOr(inst_bits + n_summary + w, 1u << (c[k].ref & 31));
+                        atomicOr(inst_bits + (w >> 5), 1u << (w & 31));
+                        L.word = min(L.word, w); L.whi = max(L.whi, w);
+                    }
+                }
+                // Visit order of the reference: at each binary split the near child first, near =
+                // left iff dir[splitAxis] >= 0 (bvh.cpp:139-147).  Slots 0,1 hang under the left
+                // child (split axisL), slots 2,3 under the right child (axisR), the two pairs
+                // under the node itself (axis0).
+                const int axis0 = __double2loint(nd[28]), axisL = __double2hiint(nd[28]), axisR = __double2loint(nd[29]);
+                const double d0 = axis0 == 0 ? L.rd.x : (axis0 == 1 ? L.rd.y : L.rd.z);
+                const double dl = axisL == 0 ? L.rd.x : (axisL == 1 ? L.rd.y : L.rd.z);
+                const double dr = axisR == 0 ? L.rd.x : (axisR == 1 ? L.rd.y : L.rd.z);
+                // a leaf child occupies the first slot of its pair: nothing to order there
+                cand_swap(c[0], c[1], !(dl >= 0.0) && c[1].cnt >= 0);
+                cand_swap(c[2], c[3], !(dr >= 0.0) && c[3].cnt >= 0);
+                const bool right_first = !(d0 >= 0.0);
+                cand_swap(c[0], c[2], right_first);
+                cand_swap(c[1], c[3], right_first);
+                // c[0..3] is now near -> far.  The nearest passing child is entered; the others
+                // are pushed, farthest first, each with its entry distance for the re-check at pop.
+                const bool any0 = c[0].ok, any1 = any0 | c[1].ok, any2 = any1 | c[2].ok;
+#pragma unroll
+                for (int k = 3; k >= 1; k--) {
+                    const bool earlier = k == 3 ? any2 : (k == 2 ? any1 : any0);
+                    // (a full stack cannot happen with trees the host has accepted; if it does, the
+                    // frame is reported as failed instead of silently losing a subtree)
+                    if (c[k].ok && earlier && L.sp >= RTX_STACK) *S.limit_flag = 1u;
+                    if (c[k].ok && earlier && L.sp < RTX_STACK) {
+                        if (L.sp > 0) stk[L.sp - 1] = L.top;
+                        L.top.x = __double2loint(c[k].e); L.top.y = __double2hiint(c[k].e); L.top.z = c[k].ref; L.top.w = c[k].cnt;
+                        L.sp++;
+                    }
+                }
+                if (any2 | c[3].ok) {
+                    const int sel = any0 ? 0 : (c[1].ok ? 1 : (c[2].ok ? 2 : 3));
+                    L.cur_ref = sel == 0 ? c[0].ref : (sel == 1 ? c[1].ref : (sel == 2 ? c[2].ref : c[3].ref));
+                    L.cur_cnt = sel == 0 ? c[0].cnt : (sel == 1 ? c[1].cnt : (sel == 2 ? c[2].cnt : c[3].cnt));
+                } else {
+                    need_pop = true;
+                }
+            } else {
+                // ---- leaf: its next two triangles, in leaf order (bvh.cpp:150-170) ----------------
+                const int ti = L.cur_ref;
+                const bool two = L.cur_cnt >= 2;
+                if (COUNT) tl.tri_tests += two ? 2u : 1u;
+                const double* td = rec;
+                const double* tq = rec + 16;
+                bool culled0 = false, culled1 = false;
+                if (cull) {                                                                   // utils.cpp:322-326
+                    culled0 = L.rd.x * td[10] + L.rd.y * td[11] + L.rd.z * td[12] > 0.0;
+                    culled1 = L.rd.x * tq[10] + L.rd.y * tq[11] + L.rd.z * tq[12] > 0.0;
+                }
+                double t, b, g2;
+                if (!culled0 && tri_test(td, L.ro, L.rd, L.t_min, isect_eps, t, b, g2)) { L.t_min = t; L.btri = ti; }
+                if (two && !culled1 && tri_test(tq, L.ro, L.rd, L.t_min, isect_eps, t, b, g2)) { L.t_min = t; L.btri = ti + 1; }
+                L.cur_ref += 2; L.cur_cnt -= 2;
+                need_pop = L.cur_cnt <= 0;
+                if (!COUNT && (L.is_shadow & 2) && L.btri >= 0 && L.t_min < L.orig_t_min) {
+                    need_pop = true; L.sp = 0;         // occluder found: the job ends here
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        const long long p0 = COUNT ? clock64() : 0;
+        if (need_pop) {
+            L.state = LS_JOB_DONE;
+            if (L.sp > 0) {
+                // First pop peeled off the loop: it consumes only registers, and the refill load
+                // it issues stays in flight (inside the loop every iteration has to wait for the
+                // previous iteration's refill).  Everything that reads the old top comes before
+                // the load, so the load can target the registers that hold it.
+                int pass = L.t_min >= __hiloint2double(L.top.y, L.top.x) ? 1 : 0;
+                if (pass) { L.cur_ref = L.top.z; L.cur_cnt = L.top.w; L.state = LS_IN_JOB; }
+                asm volatile("" : "+v"(pass), "+v"(L.cur_ref), "+v"(L.cur_cnt), "+v"(L.state));   // old top is dead from here
+                --L.sp;
+                L.top = stk[L.sp > 0 ? L.sp - 1 : 0];          // (entry 0 is always readable)
+                if (!pass) {
+                    // The entry failed its re-check.  After a hit has pulled the bound in, most of
+                    // what is left on the stack fails too, one entry after the other: the entries
+                    // are examined four at a time (adjacent in memory, one round trip; the first
+                    // of them is the refill already in flight), from the top down.
+                    while (L.sp > 0) {
+                        const v4i e1 = stk[L.sp >= 2 ? L.sp - 2 : 0];
+                        const v4i e2 = stk[L.sp >= 3 ? L.sp - 3 : 0];
+                        const v4i e3 = stk[L.sp >= 4 ? L.sp - 4 : 0];
+                        const bool p0 = L.t_min >= __hiloint2double(L.top.y, L.top.x);
+                        const bool p1 = L.sp >= 2 && L.t_min >= __hiloint2double(e1.y, e1.x);
+                        const bool p2 = L.sp >= 3 && L.t_min >= __hiloint2double(e2.y, e2.x);
+                        const bool p3 = L.sp >= 4 && L.t_min >= __hiloint2double(e3.y, e3.x);
+                        const int k = p0 ? 0 : (p1 ? 1 : (p2 ? 2 : (p3 ? 3 : 4)));     // first that passes; 4: none
+                        if (k < 4) {
+                            L.cur_ref = k == 0 ? L.top.z : (k == 1 ? e1.z : (k == 2 ? e2.z : e3.z));
+                            L.cur_cnt = k == 0 ? L.top.w : (k == 1 ? e1.w : (k == 2 ? e2.w : e3.w));
+                            L.state = LS_IN_JOB;
+                        }
+                        const int used = k < 4 ? k + 1 : 4;
+                        L.sp = L.sp > used ? L.sp - used : 0;
+                        if (L.sp > 0) {                   // the new top: the entry below the last one used
+                            if (k == 0) L.top = e1;
+                            else if (k == 1) L.top = e2;
+                            else if (k == 2) L.top = e3;
+                            else L.top = stk[L.sp - 1];
+                        }
+                        if (k < 4) break;
+                    }
+                }
+            }
+        }
+        if (COUNT) tl.clk_pop += (unsigned long long)(clock64() - p0);
+    }
+    return 0ull;
+}
+
+// WIDE = 2: the variant for generations of at most RTX_WIDE_MAX_RAYS rays, all of whose last
+// jobs are traversed wave-wide (wide_job).  It and a main variant are launched for every
+// generation and exactly one of them does the work; the other returns at once.
+// WIDE = 1: main variant in which drained waves finish their long-running jobs wave-wide too.
+// WIDE = 0: main variant without any of it.  (Variants rather than branches: the mere presence
+// of the call changes the register allocation of the code around it -- the service passes pay
+// for it, which scenes dominated by instance replay notice -- so the host picks per scene.)
+template <bool COUNT, int WIDE, bool FAST>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RTX_TRACE_WAVES, RTX_TRACE_WAVES)))
+k_trace(const Launch* __restrict__ Lp, GenCtrl* ctrl, const int gen, double* __restrict__ accum,
+        rtx_hit_id* __restrict__ aov, Counters* __restrict__ counters) {
+    const Scene& S = Lp->S;
+    const Frame& F = Lp->F;
+    const Queue& qin = Lp->q[(gen + 1) & 1];
+    __shared__ __attribute__((aligned(16))) double lds_rows[4][64 * RTX_ROW_DOUBLES];      // 64 KB per block
+    Wave wv;
+    // (wave-uniform by construction; saying so keeps the LDS-DMA destinations in scalar registers)
+    wv.rows = (lds_double*)(size_t)__builtin_amdgcn_readfirstlane((int)(size_t)(lds_double*)&lds_rows[threadIdx.x >> 6][0]);
+    wv.lane = lane_id();
+    const unsigned lane = wv.lane;
+    GenCtrl* me = ctrl + gen;
+    // A generation whose queue overflowed while it was being filled is incomplete, and the slots
+    // its counters claim beyond the queue were never written: it is not traced (k_shade hands the
+    // flag on, so every later generation stops too, and the host renders the frame again).
+    if (gen != 0 && me->overflow != 0u) return;
+    GenItems items;
+    unsigned n_in;
+    if (gen == 0) n_in = (unsigned)F.n_items0;
+    else { items.load(me, qin.sub_capacity); n_in = items.n_in; }
+    if (!COUNT) {
+        const bool tiny = Lp->wide_ok != 0 && n_in <= RTX_WIDE_MAX_RAYS;
+        if (tiny != (WIDE == 2)) return;
+    }
+    __shared__ __attribute__((aligned(16))) double lds_objs[RTX_LDS_OBJS * (sizeof(Obj) / 8)];
+    ObjCache oc;
+    oc.lds = (const Obj*)lds_objs;
+    oc.n = min(S.n_meshes + S.n_insts, RTX_LDS_OBJS);
+    __shared__ double lds_ctx[256 * 5];
+    oc.ctx = lds_ctx + threadIdx.x * 5;
+    for (unsigned i = threadIdx.x; i < (unsigned)oc.n * (unsigned)(sizeof(Obj) / 16); i += blockDim.x)
+        ((v2d*)lds_objs)[i] = ((const RTX_GLOBAL v2d*)S.objs)[i];
+    __syncthreads();
+    Tally tl = {};
+    const long long clk_begin = COUNT ? clock64() : 0;
+
+    // Rays are claimed in chunks (one atomic per chunk per wave) and handed to lanes as they
+    // fall idle.  A thin generation is latency bound: smaller chunks spread it over more waves.
+    // Chunks shrink as the generation drains (guided scheduling: a share of what the last claim
+    // saw remaining), so that no wave is left with several rounds of rays when the others run dry.
+    const unsigned n_waves = gridDim.x * (blockDim.x >> 6);
+    unsigned chunk = (n_in + 2u * n_waves - 1u) / (2u * n_waves);
+    const unsigned chunk_max = Lp->chunk_max;
+    chunk = chunk < 1u ? 1u : (chunk > chunk_max ? chunk_max : chunk);
+    unsigned chunk_next = 0, chunk_end = 0;      // wave-uniform
+    bool drained = false;                        // wave-uniform: the generation has no rays left
+
+    glob_v4i* const stk = (glob_v4i*)Lp->stacks +
+                          ((size_t)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 64u + lane) * RTX_STACK;
+    unsigned* const inst_bits = Lp->inst_bits + ((size_t)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 64u + lane) * Lp->inst_words;
+    const int service_threshold = (int)Lp->service_threshold;
+    const bool thin = gen != 0 && n_in < RTX_SCATTER_THIN_RAYS;
+    const int wide_lanes = thin ? RTX_WIDE_LANES_THIN : RTX_WIDE_LANES, wide_age = thin ? RTX_WIDE_AGE_THIN : RTX_WIDE_AGE;
+    Lane L;
+    L.state = LS_EMPTY; L.cur_cnt = 0; L.cur_ref = 0; L.sp = 0; L.slot = 0; L.is_shadow = 0; L.btri = -1; L.obj = 0;
+    L.top = (v4i)(0); L.t_min = 0.0; L.ro = mk(0, 0, 0); L.rd = mk(0, 0, 1); L.ix = L.iy = L.iz = 0.0; L.par = 0;
+    L.o = mk(0, 0, 0); L.d = mk(0, 0, 1); L.it = 0; L.word = 0; L.whi = -1; L.bits = 0u; L.sword = 0; L.sbits = 0u; L.age = 0;
+
+    while (true) {
+        const int state = L.state;
+        const unsigned long long m_empty = __ballot(state == LS_EMPTY);
+        const unsigned long long m_need = __ballot(state == LS_NEED_JOB || state == LS_JOB_DONE);
+        const unsigned long long m_trav = __ballot(state == LS_IN_JOB);
+        const int n_service = __popcll(m_need) + (drained ? 0 : __popcll(m_empty));
+
+        if (n_service > 0 && (m_trav == 0ull || n_service >= service_threshold)) {
+            // ---- service pass ---------------------------------------------------------------
+            const long long c0 = COUNT ? clock64() : 0;
+            for (int rep = 0; rep < RTX_SERVICE_REPS; rep++) {
+                const unsigned long long me_ = __ballot(L.state == LS_EMPTY);
+                bool fresh = false;
+                if (me_ != 0ull && !drained) {
+                    if (chunk_next == chunk_end) {
+                        unsigned base = 0;
+                        if (lane == 0) base = atomicAdd(&me->head_trace, chunk);
+                        base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
+                        if (base >= n_in) { drained = true; chunk_next = chunk_end = 0; }
+                        else {
+                            chunk_next = base; chunk_end = min(base + chunk, n_in);
+                            const unsigned share = (n_in - chunk_end) / (2u * n_waves);
+                            chunk = share < 16u ? 16u : (share > chunk_max ? chunk_max : share);
+                            if (chunk > n_in) chunk = n_in;
+                        }
+                    }
+                    if (!drained) {
+                        const unsigned take = min((unsigned)__popcll(me_), chunk_end - chunk_next);
+                        const unsigned rank = (unsigned)__popcll(me_ & ((1ull << lane) - 1ull));
+                        if (L.state == LS_EMPTY && rank < take) {
+                            const unsigned item = chunk_next + rank;
+                            if (gen == 0) {
+                                int px, py; unsigned pixel;
+                                L.slot = item; L.is_shadow = 0;
+                                if (primary_pixel(F, item, px, py, pixel)) {
+                                    L.o = ld3(F.e); L.d = primary_direction(F, px, py); fresh = true;
+                                } else {
+                                    ((RTX_GLOBAL Hit*)Lp->hb.recs + item)->code = -2;      // padding item outside the image
+                                }
+                            } else {
+                                bool sh;
+                                L.slot = items.slot(item, sh);
+                                L.is_shadow = sh ? 1 : 0;
+                                const RTX_GLOBAL Ray* r = (const RTX_GLOBAL Ray*)qin.rays + L.slot;
+                                L.o = mk(r->o[0], r->o[1], r->o[2]);
+                                L.d = mk(r->d[0], r->d[1], r->d[2]);
+                                if (sh) {
+                                    oc.ctx[0] = r->aux; oc.ctx[1] = r->w[0]; oc.ctx[2] = r->w[1]; oc.ctx[3] = r->w[2];
+                                    oc.ctx[4] = __hiloint2double(0, (int)r->pixel);
+                                }
+                                fresh = true;
+                            }
+                        }
+                        chunk_next += take;
+                    }
+                }
+                if (fresh || L.state == LS_JOB_DONE || L.state == LS_NEED_JOB)
+                    service_lane<COUNT, FAST, (WIDE == 0 && !COUNT) ? RTX_REPLAY_CAP : 0>(Lp, oc, gen, accum, aov, L, inst_bits, fresh, tl);
+                if (drained || __ballot(L.state == LS_EMPTY) == 0ull) break;
+            }
+            if (COUNT) { tl.clk_serv += (unsigned long long)(clock64() - c0); tl.passes++; }
+            continue;
+        }
+        if (m_trav == 0ull) break;
+        const long long c1 = COUNT ? clock64() : 0;
+        const unsigned long long m_wide = traverse_steps<COUNT, WIDE>(S, wv, L, stk, inst_bits, service_threshold, !drained, wide_lanes, wide_age, tl);
+        if (!COUNT && WIDE != 0 && m_wide != 0ull) wide_jobs(S, wv, L, stk, inst_bits, m_wide);
+        if (COUNT) tl.clk_trav += (unsigned long long)(clock64() - c1);
+    }
+
+    if (COUNT && counters) {
+        const bool l0 = lane == 0;
+        unsigned long long v[46] = {tl.rays, tl.primary, tl.shadow, tl.secondary, tl.node_visits, tl.tri_tests,
+                                    tl.world_box, tl.obj_trav, tl.tlas_visits, tl.inner_steps, tl.inner_lanes,
+                                    tl.leaf_steps, tl.leaf_lanes, l0 ? tl.passes : 0u, l0 ? tl.clk_trav : 0ull,
+                                    l0 ? tl.clk_serv : 0ull, l0 ? (unsigned long long)(clock64() - clk_begin) : 0ull,
+                                    l0 ? 1ull : 0ull, l0 ? tl.clk_fetch : 0ull, l0 ? tl.clk_pop : 0ull, 0ull, 0ull,
+                                    tl.sec[0], tl.sec[1], tl.sec[2], tl.sec[3], tl.sec[4], tl.sec[5], tl.sec[6], tl.sec[7],
+                                    tl.hist[0], tl.hist[1], tl.hist[2], tl.hist[3], tl.hist[4], tl.hist[5], tl.hist[6], tl.hist[7],
+                                    tl.hist_shadow[0], tl.hist_shadow[1], tl.hist_shadow[2], tl.hist_shadow[3], tl.hist_shadow[4],
+                                    tl.hist_shadow[5], tl.hist_shadow[6], tl.hist_shadow[7]};
+#pragma unroll
+        for (int k = 0; k < 46; k++) {
+            unsigned long long x = v[k];
+            for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off);
+            if (lane == 0 && x) atomicAdd(((unsigned long long*)counters) + k, x);
+        }
+        {
+            unsigned long long x = tl.longest_ray;
+            for (int off = 32; off > 0; off >>= 1) { const unsigned long long y = __shfl_down(x, off); x = y > x ? y : x; }
+            if (lane == 0 && x) atomicMax(&counters->longest_ray, x);
+        }
+        if (lane == 0) {
+            const unsigned long long life = (unsigned long long)(clock64() - clk_begin);
+            const unsigned long long prev = atomicMax(&counters->max_wave_ticks, life);
+            if (life > prev) counters->max_wave_steps = tl.inner_steps + tl.leaf_steps + ((unsigned long long)tl.passes << 32);
+        }
+    }
 }
 
 // Shading of the radiance hits of one generation (utils.cpp:868-1061) and emission of the
