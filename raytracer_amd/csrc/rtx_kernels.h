@@ -917,10 +917,23 @@ struct GenItems {
     }
 };
 
+// A pixel's colour is the sum of the contributions of the rays of its tree (utils.cpp:868-1061),
+// which arrive here in no fixed order.  They are accumulated as 64-bit fixed-point numbers (30
+// fraction bits): integer addition does not depend on the order, so a frame is the same bytes
+// whenever and however it is rendered -- whole, in tiles, on one GPU or on eight.  A contribution
+// is rounded to 2^-30 (nine orders of magnitude below the 8-bit quantisation step) and limited to
+// +-2^20 (the picture clamps at 255), which leaves room for 8192 such contributions per pixel.
+#define RTX_ACCUM_SCALE 1073741824.0        // 2^30
+RTX_DEV long long to_fixed(double c) {
+    c = c > 1048576.0 ? 1048576.0 : (c < -1048576.0 ? -1048576.0 : c);      // (a NaN fails both tests and becomes 0 below)
+    return c == c ? __double2ll_rn(c * RTX_ACCUM_SCALE) : 0ll;
+}
 RTX_DEV void add_color(double* accum, unsigned pixel, V3 c) {
-    if (c.x != 0.0) atomicAdd(accum + 3 * (size_t)pixel, c.x);
-    if (c.y != 0.0) atomicAdd(accum + 3 * (size_t)pixel + 1, c.y);
-    if (c.z != 0.0) atomicAdd(accum + 3 * (size_t)pixel + 2, c.z);
+    unsigned long long* acc = (unsigned long long*)accum + 3 * (size_t)pixel;
+    const long long x = to_fixed(c.x), y = to_fixed(c.y), z = to_fixed(c.z);
+    if (x != 0ll) atomicAdd(acc, (unsigned long long)x);
+    if (y != 0ll) atomicAdd(acc + 1, (unsigned long long)y);
+    if (z != 0ll) atomicAdd(acc + 2, (unsigned long long)z);
 }
 
 // Generation-0 work item -> pixel.  64 consecutive items form an 8x8 pixel block of one tile,
@@ -1913,7 +1926,7 @@ k_shade(const Launch* __restrict__ Lp, GenCtrl* ctrl, const int gen, double* __r
 __global__ void k_resolve(const double* __restrict__ accum, uint8_t* __restrict__ rgb, unsigned n_values) {
     const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_values) return;
-    double c = accum[i];
+    double c = (double)((const long long*)accum)[i] / RTX_ACCUM_SCALE;
     if (c < 0) c = 0;
     if (c > 255) c = 255;
     rgb[i] = (uint8_t)round(c);

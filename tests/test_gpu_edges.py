@@ -104,7 +104,7 @@ def test_many_tiny_tiles(tmp_path):
             if packed.size:
                 rt.unpack_tiles(packed, cam.width, cam.height, tile[0], tile[1], rank, world, frame)
         same, mx = ck.image_diff(frame, full)
-        assert mx <= 1 and same >= 0.995, (tile, world, same, mx)
+        assert mx == 0 and same == 1.0, (tile, world, same, mx)
     ds.close(); hs.close()
 
 
@@ -125,7 +125,7 @@ def test_queues_regrow_when_a_larger_frame_follows(tmp_path):
     assert st2["queue_overflows"] == 0
     assert np.array_equal(hits, hits2)
     same, mx = ck.image_diff(rgb, rgb2)
-    assert mx <= 1 and same >= 0.9999
+    assert mx == 0 and same == 1.0
     o_rgb, o_hits, _, _ = ck.oracle_render(hs.desc, big)
     assert len(ck.compare_hits(hits, o_hits, allow_src_unknown=False)) == 0
     same, mx = ck.image_diff(rgb, o_rgb)

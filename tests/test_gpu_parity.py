@@ -82,7 +82,7 @@ def test_device_matches_oracle_without_counters(rendered, name):
             assert len(ck.compare_hits(hits, o_hits, allow_src_unknown=False)) == 0
             _check_image(name, rgb, o_rgb)
             same, mx = ck.image_diff(rgb, rgb_counted)
-            assert mx <= 1 and same >= MIN_SAME, f"{name}: modes differ: {same:.5f} identical, max delta {mx}"
+            assert mx == 0 and same == 1.0, f"{name}: modes differ: {same:.5f} identical, max delta {mx}"
     finally:
         ds.set_counters(True)
 
@@ -143,8 +143,7 @@ def test_render_is_deterministic_and_repeatable(rendered):
     cam, rgb, hits, _ = frames[0]
     rgb2, hits2, _ = ds.render(cam, want_hits=True)
     assert np.array_equal(hits, hits2)
-    same, mx = ck.image_diff(rgb, rgb2)
-    assert mx <= 1 and same >= 0.9999
+    assert np.array_equal(rgb, rgb2)              # pixel sums are accumulated in fixed point: no dependence on arrival order
 
 
 def test_queue_regrows_after_overflow(unit_scenes):
