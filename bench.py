@@ -531,7 +531,14 @@ def measure_static(R: Rank, args, name, mode, steps, warmup, with_cpu):
     rays_rank = int(cst["rays"])
     sample_f = cpu_sample_factor(hs.desc, cam)
     ref_counts = o_rgb = o_hits = None
-    ocam = cam if sample_f == 1 else reduced_camera(cam, sample_f)
+    ocam = cam
+    if sample_f > 1:
+        # the view the bounded CPU legs render: the camera of the scene file with its resolution
+        # reduced (the reference derives the near plane from the file's own aspect ratio), so that
+        # oracle, device and the reference's PPM are pictures of exactly the same camera
+        small = rt.HostScene(reduced_scene_file(path, sample_f))
+        ocam, _ = small.camera(0)
+        small.close()
     if mode == "frames" and (rank == 0 or world == 1):
         R.note(f"reference work counts on the host (sample factor {sample_f})")
         ref_counts, o_rgb, o_hits, _ = oracle_frame(hs.desc, ocam, R.host_threads, want_hits=True)
@@ -608,15 +615,15 @@ def measure_static(R: Rank, args, name, mode, steps, warmup, with_cpu):
         achieved = bytes_per_launch / t_launch / 1e9 if t_launch > 0 else 0.0
         t_trace_frame = trace_ms / steps * 1e-3
         traffic = None
-        tfile = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tfile):
+        for tfile in (os.path.join(ROOT, "profiles", f"r02_{name}_traffic.json"), os.path.join(ROOT, "profiles", "traffic.json")):
             try:
                 with open(tfile) as f:
                     tj = json.load(f)
                 if tj.get("workload") == name:
                     traffic = tj.get("hbm_bytes_per_launch")
+                    break
             except Exception:
-                traffic = None
+                continue
         tflops = flops / t_trace_frame / 1e12 if t_trace_frame > 0 else 0.0
         roofline = {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
