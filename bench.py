@@ -501,7 +501,7 @@ def pmc_summary(workload):
         return None
 
 
-def measure_static(R: Rank, args, name, mode, steps, warmup, with_cpu):
+def measure_static(R: Rank, args, name, mode, steps, warmup, with_cpu, pipelined=False):
     """Workloads with one scene file.  mode frames: rank r renders orbit frame r every step.
     mode tiles: all ranks render interleaved tiles of ONE frame, gathered on rank 0."""
     import numpy as np
@@ -532,14 +532,14 @@ def measure_static(R: Rank, args, name, mode, steps, warmup, with_cpu):
     sample_f = cpu_sample_factor(hs.desc, cam)
     ref_counts = o_rgb = o_hits = None
     ocam = cam
-    if sample_f > 1:
-        # the view the bounded CPU legs render: the camera of the scene file with its resolution
-        # reduced (the reference derives the near plane from the file's own aspect ratio), so that
-        # oracle, device and the reference's PPM are pictures of exactly the same camera
-        small = rt.HostScene(reduced_scene_file(path, sample_f))
-        ocam, _ = small.camera(0)
-        small.close()
     if mode == "frames" and (rank == 0 or world == 1):
+        if sample_f > 1:
+            # the view the bounded CPU legs render: the camera of the scene file with its resolution
+            # reduced (the reference derives the near plane from the file's own aspect ratio), so that
+            # oracle, device and the reference's PPM are pictures of exactly the same camera
+            small = rt.HostScene(reduced_scene_file(path, sample_f))
+            ocam, _ = small.camera(0)
+            small.close()
         R.note(f"reference work counts on the host (sample factor {sample_f})")
         ref_counts, o_rgb, o_hits, _ = oracle_frame(hs.desc, ocam, R.host_threads, want_hits=True)
     counters_agree = None
@@ -593,6 +593,35 @@ def measure_static(R: Rank, args, name, mode, steps, warmup, with_cpu):
             return last["st"]
     R.note("timed steps")
     elapsed, stats = timed(R, step, steps, warmup)
+    # Two frames in flight per GPU (throughput of a stream of frames rather than the latency of
+    # one): a second device copy of the scene and a second host thread, each rendering `steps`
+    # frames back to back; one frame's thin last generations overlap the other's full ones.
+    piped = None
+    if pipelined and mode == "frames":
+        import threading
+        k_fl = max(2, args.inflight)
+        extra = [(rt.DeviceScene(hs.desc, R.local_rank), R.pinned(cam.height * cam.width * 3).reshape(cam.height, cam.width, 3))
+                 for _ in range(k_fl - 1)]
+        for d, f in extra:
+            d.render(cam, out=f)
+
+        def burst(d, f):
+            for _ in range(steps):
+                d.render(cam, out=f)
+        R.barrier()
+        t0 = time.perf_counter()
+        threads = [threading.Thread(target=burst, args=(d, f)) for d, f in extra]
+        for t in threads:
+            t.start()
+        burst(ds, frame)
+        for t in threads:
+            t.join()
+        R.barrier()
+        el2 = R.reduce([time.perf_counter() - t0], "max")[0]
+        for d, _ in extra:
+            d.close()
+        piped = {"frames_in_flight_per_gpu": k_fl, "frames": k_fl * steps * world, "wall_s": el2,
+                 "ms_per_frame_per_gpu": el2 / (k_fl * steps) * 1e3}
     kernel_ms = sum(s["kernel_ms"] for s in stats)
     trace_ms = sum(s["trace_ms"] for s in stats)
     trace_launches = sum(s["trace_launches"] for s in stats)
@@ -680,6 +709,9 @@ def measure_static(R: Rank, args, name, mode, steps, warmup, with_cpu):
                                     if args.consistent else "reference-exact (default)"},
             "roofline": roofline,
         }
+        if piped is not None:
+            piped["Mrays_per_s"] = rays_step * piped["frames_in_flight_per_gpu"] * steps / piped["wall_s"] / 1e6
+            out["frames_in_flight"] = piped
         if with_cpu:
             R.note("reference CPU renderer")
             cb, ref_img = cpu_reference_baseline(path, rays_rank, sample_f)
@@ -695,11 +727,16 @@ def measure_static(R: Rank, args, name, mode, steps, warmup, with_cpu):
     return out
 
 
-def measure_sequence(R: Rank, args, name, steps, warmup, whole):
+def measure_sequence(R: Rank, args, name, steps, warmup, whole, inflight=1):
     """camera_around_david: rank r renders frames r, r + N, ... of the 360-frame sequence through
     the animation pipeline (geometry loaded and uploaded once per rank; per frame the scene
     file is re-read for camera and lights only).  whole: every frame of the sequence once
-    (steps is ignored); otherwise `steps` frames per rank after `warmup` earlier ones."""
+    (steps is ignored); otherwise `steps` frames per rank after `warmup` earlier ones.
+    inflight > 1: that many frames of a rank are in flight at once, each on a pipeline of its own
+    (host scene, device scene, image buffer, host thread): while one frame's last, thin ray
+    generations drain -- a few long rays in an otherwise idle GPU -- the next frame's full
+    generations run beside them."""
+    import threading
     import raytracer_amd as rt
     from raytracer_amd import distributed as D
     world, rank = R.world, R.rank
@@ -716,31 +753,53 @@ def measure_sequence(R: Rank, args, name, steps, warmup, whole):
     descr = files[needed[0]][1]
     R.note(f"sequence {name}: loading the geometry once per rank")
     t0 = time.time()
-    hs = rt.HostScene(files[mine[0]][0])
-    ds = rt.DeviceScene(hs.desc, R.local_rank)
+    pipes = []
+    for _ in range(max(1, inflight)):
+        hs = rt.HostScene(files[mine[0]][0])
+        ds = rt.DeviceScene(hs.desc, R.local_rank)
+        cam, _ = hs.camera(0)
+        pipes.append((hs, ds, R.pinned(cam.height * cam.width * 3).reshape(cam.height, cam.width, 3)))
     t_setup = time.time() - t0
-    cam, _ = hs.camera(0)
-    frame = R.pinned(cam.height * cam.width * 3).reshape(cam.height, cam.width, 3)
+    hs, ds, _ = pipes[0]
 
-    def render(f, counters=False):
-        if not hs.load_next(files[f][0]):
+    def render(f, pipe=0):
+        phs, pds, pframe = pipes[pipe]
+        if not phs.load_next(files[f][0]):
             raise SystemExit(f"frame {f}: the geometry was not kept")
-        ds.update_lights(hs.lights())
-        c, _ = hs.camera(0)
-        return ds.render(c, out=frame)[2]
+        pds.update_lights(phs.lights())
+        c, _ = phs.camera(0)
+        return pds.render(c, out=pframe)[2]
 
-    R.note("sequence: device counting pass")
-    ds.set_counters(True)
-    rays_mine = sum(int(render(f)["rays"]) for f in mine)
-    ds.set_counters(False)
-    R.note("sequence: timed frames")
-    for f in warm:
-        render(f)
+    def render_all(frames):
+        """frames dealt round-robin to the pipelines, one host thread each -> list of rtx_stats"""
+        if len(pipes) == 1:
+            return [render(f) for f in frames]
+        results, errors = [[] for _ in pipes], []
+
+        def work(p):
+            try:
+                results[p] = [render(f, p) for f in frames[p::len(pipes)]]
+            except BaseException as e:      # noqa: BLE001 - reported by the caller's thread
+                errors.append(e)
+        threads = [threading.Thread(target=work, args=(p,)) for p in range(len(pipes))]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        if errors:
+            raise errors[0]
+        return [s for r in results for s in r]
+
+    # rays need no device counters (rtx_stats fills them from the queue fill levels), so the
+    # timed frames themselves give the count
+    R.note(f"sequence: timed frames ({len(pipes)} in flight)")
+    render_all(warm * len(pipes))
     R.barrier()
     t0 = time.perf_counter()
-    stats = [render(f) for f in mine]
+    stats = render_all(mine)
     R.barrier()
     elapsed = R.reduce([time.perf_counter() - t0], "max")[0]
+    rays_mine = sum(int(s["rays"]) for s in stats)
     rays_all, frames_all = R.reduce([rays_mine, len(mine)])
     out = None
     if rank == 0:
@@ -748,15 +807,16 @@ def measure_sequence(R: Rank, args, name, steps, warmup, whole):
         out = {"workload": name, "description": descr,
                "sharding": "whole frames: frame f of the sequence on rank f mod N, no collective; geometry parsed, built "
                            "and uploaded once per rank, camera and lights re-read per frame",
-               "frames": int(frames_all), "frames_per_rank": per_rank, "wall_s": elapsed,
+               "frames": int(frames_all), "frames_per_rank": per_rank, "frames_in_flight_per_gpu": len(pipes), "wall_s": elapsed,
                "frames_per_s": frames_all / elapsed, "ms_per_frame_per_gpu": elapsed / per_rank * 1e3,
                "Mrays_per_s": rays_all / elapsed / 1e6, "rays": int(rays_all), "resolution": [cam.width, cam.height],
                "setup_s_per_rank": t_setup, "kernel_ms_per_frame": sum(s["kernel_ms"] for s in stats) / max(len(stats), 1),
                "trace_ms_per_frame": sum(s["trace_ms"] for s in stats) / max(len(stats), 1),
                "trace_launches_per_frame": sum(s["trace_launches"] for s in stats) / max(len(stats), 1),
                "n_gpus": world}
-    ds.close()
-    hs.close()
+    for phs, pds, _ in pipes:
+        pds.close()
+        phs.close()
     return out
 
 
@@ -765,7 +825,7 @@ def run_rank(args) -> int:
     world = R.world
     extras = (not args.no_extras and args.workload == "dragon_metal" and args.mode == "frames" and not args.consistent)
     if is_sequence(args.workload):
-        seq = measure_sequence(R, args, args.workload, args.steps, args.warmup, whole=False)
+        seq = measure_sequence(R, args, args.workload, args.steps, args.warmup, whole=False, inflight=args.inflight)
         out = None
         if R.rank == 0:
             out = {"metric": "Mrays/s (ms/frame in ms_per_step)", "value": seq["Mrays_per_s"], "unit": "Mrays/s",
@@ -777,13 +837,16 @@ def run_rank(args) -> int:
                    "sequence": seq}
     else:
         out = measure_static(R, args, args.workload, args.mode, args.steps, args.warmup,
-                             with_cpu=(world == 1 and not args.no_cpu_baseline))
+                             with_cpu=(world == 1 and not args.no_cpu_baseline), pipelined=extras or args.pipelined)
     if extras:
         # the two other shardings of the path, measured after the main one and reported beside it
         seq = measure_sequence(R, args, "camera_around_david", 0, 0, whole=True)
+        seq2 = measure_sequence(R, args, "camera_around_david", 0, 0, whole=True, inflight=3)
         tiles = measure_static(R, args, "grass_desert", "tiles", 5, 1, with_cpu=False)
         if R.rank == 0:
             out["sequence"] = seq
+            out["sequence"]["frames_in_flight"] = {k: seq2[k] for k in ("frames_in_flight_per_gpu", "wall_s", "frames_per_s",
+                                                                         "ms_per_frame_per_gpu", "Mrays_per_s")}
             out["tiled_frame"] = {k: tiles[k] for k in ("value", "unit", "ms_per_step", "n_gpus", "steps", "scaling")}
             out["tiled_frame"].update({"workload": "grass_desert", "sharding": tiles["config"]["sharding"],
                                        "resolution": tiles["config"]["resolution"],
@@ -812,6 +875,10 @@ def parse_args(argv=None):
                     help="time the library's consistent mode (NOT the reference's results for scaled instances; "
                          "never the headline number).  Rays and algorithmic bytes stay those of the same frame in "
                          "the default, reference-exact mode")
+    ap.add_argument("--inflight", type=int, default=1,
+                    help="frames in flight per GPU: for camera_around_david as the main workload (default 1), and for --pipelined")
+    ap.add_argument("--pipelined", action="store_true",
+                    help="also measure the workload with several frames in flight per GPU (--inflight, at least 2; reported as frames_in_flight)")
     ap.add_argument("--selftest-ranks", action="store_true",
                     help="check the rank launch path only: rendezvous over gloo, no GPU work")
     ap.add_argument("--selftest-fail-rank", type=int, default=-1, help=argparse.SUPPRESS)

@@ -40,7 +40,7 @@ def test_animation_pipeline_equals_frame_by_frame_runs(tmp_path):
     json.dump(doc, open(frames[3], "w"))
     together, single = os.path.join(d, "together"), os.path.join(d, "single")
     os.makedirs(together); os.makedirs(single)
-    out = run_cli(frames + ["--out", together, "--png"])
+    out = run_cli(frames + ["--out", together, "--png", "--inflight", "1"])
     assert out.count("geometry kept") == 2                       # frames 1, 2 (4 reloads after 3)
     for f in frames:
         run_cli([f, "--out", single, "--quiet"])
@@ -90,7 +90,7 @@ def test_gpu_build_flag_gives_the_same_pictures(tmp_path):
     host_dir, dev_dir = os.path.join(d, "host"), os.path.join(d, "dev")
     os.makedirs(host_dir); os.makedirs(dev_dir)
     run_cli(frames + ["--out", host_dir, "--quiet"])
-    out = run_cli(frames + ["--out", dev_dir, "--gpu-build"])
+    out = run_cli(frames + ["--out", dev_dir, "--gpu-build", "--inflight", "1"])
     assert out.count("geometry kept") == 1
     for k in range(2):
         a = read_p3(os.path.join(host_dir, f"davids_camera_{k:03d}.ppm"))
@@ -130,3 +130,20 @@ def test_frame_split_over_devices_and_resolution_override(tmp_path):
     same, mx = ck.image_diff(c, o_big)
     assert mx <= 2 and same >= 0.999, (same, mx)
     hs.close()
+
+
+def test_frames_in_flight_give_the_same_files(tmp_path):
+    """--inflight K: K pipelines (own loaded scene, device copy, host thread) take the frames in turn;
+    the pictures are the same bytes as one pipeline's."""
+    d = str(tmp_path)
+    frames = [scenes.scene_david_frame(d, f, n_frames=12, faces=3000, res=(64, 48)) for f in range(7)]
+    outs = {}
+    for k in (1, 3):
+        o = os.path.join(d, f"inflight{k}")
+        os.makedirs(o)
+        text = run_cli(frames + ["--out", o, "--inflight", str(k)])
+        assert text.count("rendered in") == 7
+        outs[k] = o
+    for f in range(7):
+        name = f"davids_camera_{f:03d}.ppm"
+        assert open(os.path.join(outs[1], name), "rb").read() == open(os.path.join(outs[3], name), "rb").read()
