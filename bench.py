@@ -599,7 +599,7 @@ def measure_static(R: Rank, args, name, mode, steps, warmup, with_cpu, pipelined
     piped = None
     if pipelined and mode == "frames":
         import threading
-        k_fl = max(2, args.inflight)
+        k_fl = args.inflight if args.inflight > 1 else 3
         extra = [(rt.DeviceScene(hs.desc, R.local_rank), R.pinned(cam.height * cam.width * 3).reshape(cam.height, cam.width, 3))
                  for _ in range(k_fl - 1)]
         for d, f in extra:
