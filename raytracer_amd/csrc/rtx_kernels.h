@@ -1523,9 +1523,12 @@ RTX_DEV unsigned long long traverse_steps(const Scene& S, const Wave& wv, Lane& 
                     // are examined four at a time (adjacent in memory, one round trip; the first
                     // of them is the refill already in flight), from the top down.
                     while (L.sp > 0) {
-                        const v4i e1 = stk[L.sp >= 2 ? L.sp - 2 : 0];
-                        const v4i e2 = stk[L.sp >= 3 ? L.sp - 3 : 0];
-                        const v4i e3 = stk[L.sp >= 4 ? L.sp - 4 : 0];
+                        v4i e1 = stk[L.sp >= 2 ? L.sp - 2 : 0];
+                        v4i e2 = stk[L.sp >= 3 ? L.sp - 3 : 0];
+                        v4i e3 = stk[L.sp >= 4 ? L.sp - 4 : 0];
+                        // (each entry stays the one 16-byte load it is: left to itself the compiler
+                        // fetches the distance halves a second time, one dependent round trip each)
+                        asm volatile("" : "+v"(e1), "+v"(e2), "+v"(e3));
                         const bool p0 = L.t_min >= __hiloint2double(L.top.y, L.top.x);
                         const bool p1 = L.sp >= 2 && L.t_min >= __hiloint2double(e1.y, e1.x);
                         const bool p2 = L.sp >= 3 && L.t_min >= __hiloint2double(e2.y, e2.x);
