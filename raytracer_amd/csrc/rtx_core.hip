@@ -245,8 +245,10 @@ struct TlasItem { HBox box; int idx; double c[3]; };
 
 // TLAS over the instances' world boxes, written as Node4 records of the same array the BLAS
 // records live in: median split on the widest centroid axis, two binary levels per record.  A
-// slot with cnt == -2 is an instance (ref = instance index).  The order of the slots carries no
-// meaning: the walk only marks candidates.
+// slot with cnt == -2 is an instance (ref = instance index).  The lower side of a split goes to
+// the first slots and the split axes are recorded like a BLAS record's, so that a walk visits the
+// near side first (the consistent mode prunes with the bound as it goes; the default mode's walk
+// only marks candidates, in any order).
 struct TlasBuild {
     std::vector<TlasItem>& items;
     std::vector<Node4>& nodes;
@@ -267,7 +269,7 @@ struct TlasBuild {
     // for the first kSahLevels levels and the median below, which bounds the depth at
     // kSahLevels + 16 levels (96 entries of the RTX_STACK-entry stack).
     static constexpr int kSahLevels = 16;
-    int split(int lo, int hi, bool sah) {
+    int split(int lo, int hi, bool sah, int32_t& axis_out) {
         double cmn[3] = {1e300, 1e300, 1e300}, cmx[3] = {-1e300, -1e300, -1e300};
         for (int i = lo; i < hi; i++)
             for (int k = 0; k < 3; k++) { cmn[k] = std::min(cmn[k], items[(size_t)i].c[k]); cmx[k] = std::max(cmx[k], items[(size_t)i].c[k]); }
@@ -305,11 +307,12 @@ struct TlasBuild {
             auto mid = std::partition(items.begin() + lo, items.begin() + hi, [=](const TlasItem& a) {
                 return std::min(kBins - 1, std::max(0, (int)((a.c[k] - c0) * scale))) <= bin; });
             const int m = (int)(mid - items.begin());
-            if (m > lo && m < hi) return m;
+            if (m > lo && m < hi) { axis_out = k; return m; }
         }
         const int mid = lo + (hi - lo) / 2;
         std::nth_element(items.begin() + lo, items.begin() + mid, items.begin() + hi,
                          [axis](const TlasItem& a, const TlasItem& b) { return a.c[axis] < b.c[axis]; });
+        axis_out = axis;
         return mid;
     }
     void slot(Node4& o, int s, const HBox& box, int32_t ref, int32_t cnt) {
@@ -331,12 +334,12 @@ struct TlasBuild {
         const bool sah = level < kSahLevels;
         if (hi - lo == 1) fill(o, 0, lo, hi, level);
         else {
-            const int mid = split(lo, hi, sah);
+            const int mid = split(lo, hi, sah, o.axis0);
             const int part[3] = {lo, mid, hi};
             for (int p = 0; p < 2; p++) {
                 const int a = part[p], b = part[p + 1];
                 if (b - a == 1) { fill(o, 2 * p, a, b, level); continue; }
-                const int m2 = split(a, b, sah);
+                const int m2 = split(a, b, sah, p == 0 ? o.axisL : o.axisR);
                 fill(o, 2 * p, a, m2, level);
                 fill(o, 2 * p + 1, m2, b, level);
             }
@@ -861,6 +864,8 @@ int render_frame(rtx_scene* sc, const rtx_camera* cam, int32_t tw, int32_t th, i
         launch.service_threshold = sc->dev.n_insts >= 256 ? RTX_SERVICE_THRESHOLD_INSTANCED : RTX_SERVICE_THRESHOLD;
         // wave-wide traversal of a drained generation's last jobs: its visiting-order keys hold 26 record levels
         launch.wide_ok = (sc->record_levels <= 26 && !getenv("RTX_AMD_NO_WIDE")) ? 1u : 0u;
+        // (consistent mode enters instances from the TLAS walk; the wave-wide traversal knows one job per ray)
+        if (sc->consistent && sc->dev.n_insts > RTX_LINEAR_INSTS) launch.wide_ok = 0u;
         // ... and, in scenes that are not dominated by instance replay, of the long-running jobs of
         // every generation's drained waves (a kernel variant of its own; see k_trace)
         launch.chunk_max = sc->dev.n_insts >= 256 ? RTX_CHUNK_INSTANCED : RTX_CHUNK; launch.pad_launch = 0;
@@ -878,8 +883,10 @@ int render_frame(rtx_scene* sc, const rtx_camera* cam, int32_t tw, int32_t th, i
         if (sc->gen_events.size() < (size_t)2 * G + 1) return fail(RTX_EHIP, "event pool smaller than the generation count");
         std::vector<hipEvent_t>& gev = sc->gen_events;
         using TraceKernel = void (*)(const Launch*, GenCtrl*, int, double*, rtx_hit_id*, Counters*);
+        const bool nest = sc->consistent && sc->dev.n_insts > RTX_LINEAR_INSTS;
         const TraceKernel trace_main =
             sc->counters_on ? k_trace<true, 0, false>
+            : nest ? k_trace<false, 0, true, true>
             : sc->consistent ? (launch.wide_old ? k_trace<false, 1, true> : k_trace<false, 0, true>)
                              : (launch.wide_old ? k_trace<false, 1, false> : k_trace<false, 0, false>);
         const TraceKernel trace_tiny = sc->consistent ? k_trace<false, 2, true> : k_trace<false, 2, false>;

@@ -553,7 +553,7 @@ RTX_DEV void ray_begin(const Scene& S, Lane& L, const RecOut& out, const double 
 // up: rayHitsMesh's prologue, utils.cpp:418-494 + the root test of bvh.cpp:132), the object
 // sequence is exhausted (returns 0), or the lane has turned down CAP instance candidates in
 // this call (returns 2: call again in the next service pass).
-template <bool COUNT, bool FAST, int CAP>
+template <bool COUNT, bool FAST, int CAP, bool NEST>
 RTX_DEV int job_next(const Scene& S, const ObjCache& oc, Lane& L, const RecOut& out, unsigned* inst_bits, const double light_dist, Tally& tl) {
     const unsigned n_summary = rtx_summary_words(S.n_insts);
     const Slab ws = make_slab(L.o, L.d);         // world-space slab constants, once per call
@@ -593,6 +593,22 @@ RTX_DEV int job_next(const Scene& S, const ObjCache& oc, Lane& L, const RecOut& 
                 // reference's own per-instance logic (world-box test against the then-current
                 // bound included).
                 L.word = INT_MAX; L.whi = -1; L.bits = 0u; L.sbits = 0u; L.sword = -1;
+                if (NEST) {
+                    // consistent mode: the walk enters the instances itself, nearest first (see
+                    // traverse_steps); word = stack base of the job inside an instance, whi = the
+                    // instance the current hit came from (-1: none, or something that is not an instance)
+                    L.word = 0; L.whi = -1;
+                    double tl_min[3] = {S.tl_min[0], S.tl_min[1], S.tl_min[2]}, tl_max[3] = {S.tl_max[0], S.tl_max[1], S.tl_max[2]};
+                    double enter;
+                    if (!box_enter(tl_min, tl_max, ws, enter) || !(L.t_min * 1.000001 >= enter)) return 0;
+                    L.obj = -1;
+                    L.is_shadow &= 1;
+                    L.age = 0;
+                    L.orig_t_min = L.t_min;
+                    L.ro = L.o; L.rd = L.d; L.ix = ws.ix; L.iy = ws.iy; L.iz = ws.iz; L.par = ws.par;
+                    L.cur_ref = S.tl_key; L.cur_cnt = 0; L.sp = 0; L.btri = -1;
+                    return 1;
+                }
                 if (S.n_insts > 0 && S.n_insts <= RTX_LINEAR_INSTS) {
                     // a handful of instances: every one is a candidate (the reference's own loop,
                     // utils.cpp:756-790); a TLAS walk would cost more than it can save
@@ -705,11 +721,75 @@ RTX_DEV int job_next(const Scene& S, const ObjCache& oc, Lane& L, const RecOut& 
     }
 }
 
+// Consistent mode, instance phase (see traverse_steps, NEST).  nest_resume: back to the walk of
+// the TLAS with the world-space ray; returns 1 if the walk has entries left (the lane asks for a
+// pop), 0 if the ray has seen every instance it can meet.
+RTX_DEV int nest_resume(Lane& L) {
+    const Slab ws = make_slab(L.o, L.d);
+    L.obj = -1; L.word = 0;
+    L.ro = L.o; L.rd = L.d; L.ix = ws.ix; L.iy = ws.iy; L.iz = ws.iz; L.par = ws.par;
+    L.btri = -1;
+    if (L.sp <= 0) return 0;
+    L.cur_ref = 0; L.cur_cnt = -1;
+    return 1;
+}
+// nest_enter: the walk has arrived at instance `idx` (its world box passed against the current
+// bound): rayHitsMesh's prologue (utils.cpp:418-494) with the bound taken to object space, and
+// the root test of bvh.cpp:132.  Returns like nest_resume when the instance is turned down.
+RTX_DEV int nest_enter(const Scene& S, const ObjCache& oc, Lane& L, const int idx) {
+    const int oi = S.n_meshes + idx;
+    const Obj* ob = oc.at(S, oi);
+    double ob2[16];
+    {
+        const v2d* p2 = (const v2d*)ob->bmin;
+#pragma unroll
+        for (int k = 3; k < 7; k++) { const v2d v = p2[k]; ob2[2 * k] = v.x; ob2[2 * k + 1] = v.y; }
+    }
+    const int root_ref = __double2loint(ob2[12]), root_count = __double2hiint(ob2[12]);
+    const int flags = __double2loint(ob2[13]);
+    if (flags & OBJ_SKIP) return nest_resume(L);
+    V3 ro = L.o, rd = L.d;
+    double bound = L.t_min;
+    // A radiance ray's bound gets a hair of slack: a hit that ties with the current one has to be
+    // found, because the instance index decides the tie (job_finalize).  World distances of
+    // transformed hits are rounded to float, so the slack is relative there and one ulp otherwise.
+    // (A shadow ray asks for any hit in front of its light: no slack.)
+    const bool shadow = L.is_shadow != 0;
+    if (flags & OBJ_XF) {
+        double inv[16];
+        {
+            const v2d* p1 = (const v2d*)ob->inv;
+#pragma unroll
+            for (int k = 0; k < 8; k++) { const v2d v = p1[k]; inv[2 * k] = v.x; inv[2 * k + 1] = v.y; }
+        }
+        ro = xf_point(inv, L.o);
+        const V3 od = xf_dir(inv, L.d);
+        rd = normalize_f32(od);
+        bound = L.t_min / (1.0 / (double)sqrtf((float)(od.x * od.x + od.y * od.y + od.z * od.z)));
+        if (!shadow) bound *= 1.000001;
+    } else if (!shadow && bound < DBL_MAX) {
+        bound = __longlong_as_double(__double_as_longlong(bound) + 1ll);
+    }
+    const Slab sl = (flags & OBJ_XF) ? make_slab(ro, rd) : make_slab(L.o, L.d);
+    double enter;
+    if (!box_enter(ob2 + 6, ob2 + 9, sl, enter) || !(bound >= enter)) return nest_resume(L);
+    L.obj = oi;
+    L.word = L.sp;                       // the walk's entries stay below the job's
+    L.orig_t_min = L.t_min;
+    L.t_min = bound;
+    L.is_shadow &= 1;
+    L.age = 0;
+    if (L.is_shadow) { L.is_shadow = 3; L.orig_t_min = bound; }      // any accepted triangle decides a shadow ray
+    L.ro = ro; L.rd = rd; L.ix = sl.ix; L.iy = sl.iy; L.iz = sl.iz; L.par = sl.par;
+    L.cur_ref = root_ref; L.cur_cnt = root_count; L.btri = -1;
+    return 1;
+}
+
 // End of a traversal job: what rayHitsMesh does after bvh->traverse returns
 // (utils.cpp:533-668), including the fields the winning triangle test wrote
 // (utils.cpp:370-381, bvh.cpp:162).  beta and gamma of the winning triangle are recomputed
 // here with the same arithmetic that accepted it (same inputs, same bits).
-template <bool FAST>
+template <bool FAST, bool NEST>
 RTX_DEV void job_finalize(const Scene& S, const ObjCache& oc, Lane& L, const RecOut& out) {
     if (L.btri < 0) {
         if (FAST) L.t_min = L.orig_t_min;         // (a transformed job ran with the object-space bound)
@@ -738,6 +818,14 @@ RTX_DEV void job_finalize(const Scene& S, const ObjCache& oc, Lane& L, const Rec
         out.kind(RTX_KIND_MESH);
     }
     if (!(flags & OBJ_XF)) {
+        if (NEST && L.it > S.n_meshes) {
+            // an untransformed instance visited out of index order (NEST): its job ran with a bound
+            // one ulp above the current one, so a hit at exactly the current distance shows up
+            // here and the lower instance index takes it
+            const int idx = L.obj - S.n_meshes;
+            if (L.t_min >= L.orig_t_min && !(idx < L.whi)) { L.t_min = L.orig_t_min; return; }
+            L.whi = idx;
+        }
         if (FAST) { out.bary(beta, gamma, face, tri); out.kind(RTX_KIND_MESH); }
         out.geom(L.t_min, point, gn, gn);
         out.owner(mat, mi);
@@ -752,12 +840,18 @@ RTX_DEV void job_finalize(const Scene& S, const ObjCache& oc, Lane& L, const Rec
     double dx = wp.x - L.o.x, dy = wp.y - L.o.y, dz = wp.z - L.o.z;
     double wd = (double)sqrtf((float)(dx * dx + dy * dy + dz * dz));
     if (FAST) {
-        // consistent mode: a hit that is not nearer than the bound leaves no trace
-        if (wd >= L.orig_t_min) { L.t_min = L.orig_t_min; return; }
+        // consistent mode: a hit that is not nearer than the bound leaves no trace.  Instances
+        // visited nearest first (NEST): among hits at the same distance the lowest instance index
+        // wins, as it does when the instances are taken in index order.
+        const bool nested = NEST && L.it > S.n_meshes;
+        const int idx = L.obj - S.n_meshes;
+        const bool tie_won = nested && wd == L.orig_t_min && idx < L.whi;
+        if (wd >= L.orig_t_min && !tie_won) { L.t_min = L.orig_t_min; return; }
+        if (nested) L.whi = idx;
         out.bary(beta, gamma, face, tri);
         out.kind(RTX_KIND_MESH);
     }
-    if (wd >= L.orig_t_min) {             // utils.cpp:567-570: bound restored, record is not
+    if (!FAST && wd >= L.orig_t_min) {    // utils.cpp:567-570: bound restored, record is not
         out.geom(L.t_min, point, gn, gn);
         out.owner(mat, mi);
         L.dist = L.t_min;
@@ -966,7 +1060,7 @@ RTX_DEV V3 primary_direction(const Frame& F, int px, int py) {
 
 // Divergent per-lane part of a service pass.  `fresh`: the lane has just been handed a new ray
 // (L.slot / L.o / L.d / L.is_shadow set).
-template <bool COUNT, bool FAST, int CAP>
+template <bool COUNT, bool FAST, int CAP, bool NEST>
 RTX_DEV void service_lane(const Launch* __restrict__ Lp, const ObjCache& oc, const int gen, double* __restrict__ accum,
                           rtx_hit_id* __restrict__ aov, Lane& L, unsigned* inst_bits, const bool fresh, Tally& tl) {
     const Scene& S = Lp->S;
@@ -982,8 +1076,13 @@ RTX_DEV void service_lane(const Launch* __restrict__ Lp, const ObjCache& oc, con
         ray_begin<COUNT>(S, L, out, FAST && L.is_shadow ? oc.ctx[0] : DBL_MAX, tl);
         if (COUNT) { const long long c = clock64(); tl.sec[0] += (unsigned long long)(c - c0); tl.sec[4]++; c0 = c; }
     }
+    // consistent mode with a TLAS: instances are entered from the walk itself (traverse_steps, NEST)
+    const bool nested = NEST && L.it > S.n_meshes;
+    int nest = -1;            // 0: the walk is over, 1: a job is set up, 2: a job inside an instance has ended
     if (L.state == LS_JOB_DONE) {
-        if (L.obj == -1) {
+        if (nested && L.obj == -1) {
+            nest = L.cur_cnt == -2 ? nest_enter(S, oc, L, L.cur_ref) : 0;
+        } else if (L.obj == -1) {
             // end of the TLAS walk: L.word .. L.whi is the range of bitmap words it marked;
             // consumption starts in front of the first summary word that covers them
             L.sword = L.word == INT_MAX ? -1 : (L.word >> 5) - 1;
@@ -995,8 +1094,9 @@ RTX_DEV void service_lane(const Launch* __restrict__ Lp, const ObjCache& oc, con
             if (L.btri >= 0) L.hit = 1;
             L.t_min = oc.ctx[0];
         } else {
-            job_finalize<FAST>(S, oc, L, out);
+            job_finalize<FAST, NEST>(S, oc, L, out);
         }
+        if (nested && nest == -1) nest = 2;
         L.state = LS_NEED_JOB;
         if (COUNT) { const long long c = clock64(); tl.sec[1] += (unsigned long long)(c - c0); tl.sec[5]++; c0 = c; }
     }
@@ -1006,7 +1106,7 @@ RTX_DEV void service_lane(const Launch* __restrict__ Lp, const ObjCache& oc, con
     double light_dist = 0.0;
     if (!COUNT && L.is_shadow) light_dist = oc.ctx[0];
     const bool decided = !COUNT && L.is_shadow && L.hit != 0 && (FAST || L.t_min < light_dist);
-    if (decided && L.it > S.n_meshes) {
+    if (decided && L.it > S.n_meshes && !nested) {
         // (the current word was cleared when it was taken; what is still set in memory: the
         // words flagged in the current summary word, and the summary words not yet taken)
         const unsigned n_summary = rtx_summary_words(S.n_insts);
@@ -1024,7 +1124,8 @@ RTX_DEV void service_lane(const Launch* __restrict__ Lp, const ObjCache& oc, con
         }
         L.bits = 0u; L.sbits = 0u; L.sword = L.whi;
     }
-    const int more = decided ? 0 : job_next<COUNT, FAST, CAP>(S, oc, L, out, inst_bits, light_dist, tl);
+    const int more = decided ? 0 : (nest == 0 || nest == 1) ? nest : nest == 2 ? nest_resume(L)
+                             : job_next<COUNT, FAST, CAP, NEST>(S, oc, L, out, inst_bits, light_dist, tl);
     if (COUNT) { const long long c = clock64(); tl.sec[2] += (unsigned long long)(c - c0); tl.sec[6]++; c0 = c; }
     if (more == 1) { L.state = LS_IN_JOB; return; }
     if (more == 2) { L.state = LS_NEED_JOB; return; }          // yielded: more candidates next time
@@ -1364,7 +1465,15 @@ RTX_DEV void wide_jobs(const Scene& S, const Wave& wv, Lane& L, glob_v4i* stk, u
     }
 }
 
-template <bool COUNT, int WIDE>
+// NEST (consistent mode): instances are not collected for a replay in index order; the TLAS walk
+// enters them itself, nearest first.  A TLAS slot that holds an instance is a child like any
+// other; when it becomes the lane's current entry (cur_cnt == -2) the lane leaves for a service
+// pass, which takes the ray to the instance's object space and starts the traversal of its BLAS
+// on top of the walk's stack entries (Lane::word = the stack depth the job started at; pops stop
+// there).  After the job the service pass takes the ray back to world space and asks for the
+// walk's next entry (cur_cnt == -1: pop, nothing to fetch).  The walk prunes with the bound as it
+// shrinks, so most instances behind the first hit are never touched.
+template <bool COUNT, int WIDE, bool NEST>
 RTX_DEV unsigned long long traverse_steps(const Scene& S, const Wave& wv, Lane& L, glob_v4i* __restrict__ stk, unsigned* inst_bits,
                             const int service_threshold, const bool refillable, const int wide_lanes, const int wide_age, Tally& tl) {
     const unsigned lane = wv.lane;
@@ -1405,23 +1514,31 @@ RTX_DEV unsigned long long traverse_steps(const Scene& S, const Wave& wv, Lane& 
         // without the detour through LDS.  Otherwise the wave fetches cooperatively.
         const long long f0 = COUNT ? clock64() : 0;
         double rec[32];
+        const bool wants = in_job && !(NEST && L.cur_cnt == -1);      // (a lane that only asks for a pop fetches nothing)
         if (__popcll(m_job) <= RTX_SPARSE_LANES) {
-            if (in_job) {
+            if (wants) {
                 const RTX_GLOBAL v2d* gp = (const RTX_GLOBAL v2d*)(blas + ((size_t)(unsigned)L.cur_ref << 7));
 #pragma unroll
                 for (int p = 0; p < 16; p++) { const v2d v = gp[p]; rec[2 * p] = v.x; rec[2 * p + 1] = v.y; }
             }
         } else {
-            coop_fetch(wv, in_job ? L.cur_ref : -1, blas);
-            if (in_job) row_read<0, 16>(wv, rec);
+            coop_fetch(wv, wants ? L.cur_ref : -1, blas);
+            if (wants) row_read<0, 16>(wv, rec);
             __builtin_amdgcn_wave_barrier();
         }
         if (COUNT) tl.clk_fetch += (unsigned long long)(clock64() - f0);
 
         bool need_pop = false;
+        // the walk of the TLAS in NEST mode compares with a bound a hair above the current one: an
+        // instance whose hit ties with the current one (world distances are rounded to float) must
+        // still be visited, because the lower instance index wins a tie whatever the visiting order
+        double t_cmp = 0.0;
+        if (NEST) t_cmp = L.obj == -1 ? L.t_min * 1.000001 : L.t_min;
         if (in_job) {
             L.age++;
-            if (!at_leaf) {
+            if (NEST && L.cur_cnt == -1) {
+                need_pop = true;
+            } else if (!at_leaf) {
                 // ---- collapsed inner node: up to four grandchildren of a binary node ------------
                 if (COUNT) { if (L.obj == -1) tl.tlas_visits++; else tl.node_visits++; }
                 const double* nd = rec;
@@ -1435,9 +1552,9 @@ RTX_DEV unsigned long long traverse_steps(const Scene& S, const Wave& wv, Lane& 
                     if (any_par) hit = box_enter(nd + 6 * k, nd + 6 * k + 3, sl, e);
                     else hit = box_enter_nopar(nd + 6 * k, nd + 6 * k + 3, sl, e);
                     c[k].e = e;
-                    const bool pass = hit & (L.t_min >= e);
-                    c[k].ok = pass & (c[k].cnt >= 0);
-                    if (pass && c[k].cnt == -2) {
+                    const bool pass = hit & ((NEST ? t_cmp : L.t_min) >= e);
+                    c[k].ok = pass & (c[k].cnt >= 0 || (NEST && c[k].cnt == -2));
+                    if (!NEST && pass && c[k].cnt == -2) {
                         // TLAS walk: the slot is a mesh instance whose world box the ray can meet
                         const int w = c[k].ref >> 5;
                         atomicOr(inst_bits + n_summary + w, 1u << (c[k].ref & 31));
@@ -1454,8 +1571,8 @@ RTX_DEV unsigned long long traverse_steps(const Scene& S, const Wave& wv, Lane& 
                 const double dl = axisL == 0 ? L.rd.x : (axisL == 1 ? L.rd.y : L.rd.z);
                 const double dr = axisR == 0 ? L.rd.x : (axisR == 1 ? L.rd.y : L.rd.z);
                 // a leaf child occupies the first slot of its pair: nothing to order there
-                cand_swap(c[0], c[1], !(dl >= 0.0) && c[1].cnt >= 0);
-                cand_swap(c[2], c[3], !(dr >= 0.0) && c[3].cnt >= 0);
+                cand_swap(c[0], c[1], !(dl >= 0.0) && (NEST ? c[1].cnt != -1 : c[1].cnt >= 0));
+                cand_swap(c[2], c[3], !(dr >= 0.0) && (NEST ? c[3].cnt != -1 : c[3].cnt >= 0));
                 const bool right_first = !(d0 >= 0.0);
                 cand_swap(c[0], c[2], right_first);
                 cand_swap(c[1], c[3], right_first);
@@ -1505,14 +1622,17 @@ RTX_DEV unsigned long long traverse_steps(const Scene& S, const Wave& wv, Lane& 
         }
         __builtin_amdgcn_wave_barrier();
         const long long p0 = COUNT ? clock64() : 0;
+        int base = 0;                  // entries below belong to the suspended walk
+        double t_pop = 0.0;            // (the leaf tests may have pulled the bound in)
+        if (NEST) { base = L.obj != -1 ? L.word : 0; t_pop = L.obj == -1 ? L.t_min * 1.000001 : L.t_min; }
         if (need_pop) {
             L.state = LS_JOB_DONE;
-            if (L.sp > 0) {
+            if (L.sp > (NEST ? base : 0)) {
                 // First pop peeled off the loop: it consumes only registers, and the refill load
                 // it issues stays in flight (inside the loop every iteration has to wait for the
                 // previous iteration's refill).  Everything that reads the old top comes before
                 // the load, so the load can target the registers that hold it.
-                int pass = L.t_min >= __hiloint2double(L.top.y, L.top.x) ? 1 : 0;
+                int pass = (NEST ? t_pop : L.t_min) >= __hiloint2double(L.top.y, L.top.x) ? 1 : 0;
                 if (pass) { L.cur_ref = L.top.z; L.cur_cnt = L.top.w; L.state = LS_IN_JOB; }
                 asm volatile("" : "+v"(pass), "+v"(L.cur_ref), "+v"(L.cur_cnt), "+v"(L.state));   // old top is dead from here
                 --L.sp;
@@ -1522,17 +1642,18 @@ RTX_DEV unsigned long long traverse_steps(const Scene& S, const Wave& wv, Lane& 
                     // what is left on the stack fails too, one entry after the other: the entries
                     // are examined four at a time (adjacent in memory, one round trip; the first
                     // of them is the refill already in flight), from the top down.
-                    while (L.sp > 0) {
+                    while (L.sp > (NEST ? base : 0)) {
+                        const int avail = NEST ? L.sp - base : L.sp;
                         v4i e1 = stk[L.sp >= 2 ? L.sp - 2 : 0];
                         v4i e2 = stk[L.sp >= 3 ? L.sp - 3 : 0];
                         v4i e3 = stk[L.sp >= 4 ? L.sp - 4 : 0];
                         // (each entry stays the one 16-byte load it is: left to itself the compiler
                         // fetches the distance halves a second time, one dependent round trip each)
                         asm volatile("" : "+v"(e1), "+v"(e2), "+v"(e3));
-                        const bool p0 = L.t_min >= __hiloint2double(L.top.y, L.top.x);
-                        const bool p1 = L.sp >= 2 && L.t_min >= __hiloint2double(e1.y, e1.x);
-                        const bool p2 = L.sp >= 3 && L.t_min >= __hiloint2double(e2.y, e2.x);
-                        const bool p3 = L.sp >= 4 && L.t_min >= __hiloint2double(e3.y, e3.x);
+                        const bool p0 = (NEST ? t_pop : L.t_min) >= __hiloint2double(L.top.y, L.top.x);
+                        const bool p1 = avail >= 2 && (NEST ? t_pop : L.t_min) >= __hiloint2double(e1.y, e1.x);
+                        const bool p2 = avail >= 3 && (NEST ? t_pop : L.t_min) >= __hiloint2double(e2.y, e2.x);
+                        const bool p3 = avail >= 4 && (NEST ? t_pop : L.t_min) >= __hiloint2double(e3.y, e3.x);
                         const int k = p0 ? 0 : (p1 ? 1 : (p2 ? 2 : (p3 ? 3 : 4)));     // first that passes; 4: none
                         if (k < 4) {
                             L.cur_ref = k == 0 ? L.top.z : (k == 1 ? e1.z : (k == 2 ? e2.z : e3.z));
@@ -1540,7 +1661,7 @@ RTX_DEV unsigned long long traverse_steps(const Scene& S, const Wave& wv, Lane& 
                             L.state = LS_IN_JOB;
                         }
                         const int used = k < 4 ? k + 1 : 4;
-                        L.sp = L.sp > used ? L.sp - used : 0;
+                        L.sp = avail > used ? L.sp - used : (NEST ? base : 0);
                         if (L.sp > 0) {                   // the new top: the entry below the last one used
                             if (k == 0) L.top = e1;
                             else if (k == 1) L.top = e2;
@@ -1552,6 +1673,8 @@ RTX_DEV unsigned long long traverse_steps(const Scene& S, const Wave& wv, Lane& 
                 }
             }
         }
+        // NEST: the lane's next entry is an instance: only a service pass can enter it
+        if (NEST && L.state == LS_IN_JOB && L.cur_cnt == -2) L.state = LS_JOB_DONE;
         if (COUNT) tl.clk_pop += (unsigned long long)(clock64() - p0);
     }
     return 0ull;
@@ -1564,7 +1687,7 @@ RTX_DEV unsigned long long traverse_steps(const Scene& S, const Wave& wv, Lane& 
 // WIDE = 0: main variant without any of it.  (Variants rather than branches: the mere presence
 // of the call changes the register allocation of the code around it -- the service passes pay
 // for it, which scenes dominated by instance replay notice -- so the host picks per scene.)
-template <bool COUNT, int WIDE, bool FAST>
+template <bool COUNT, int WIDE, bool FAST, bool NEST = false>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RTX_TRACE_WAVES, RTX_TRACE_WAVES)))
 k_trace(const Launch* __restrict__ Lp, GenCtrl* ctrl, const int gen, double* __restrict__ accum,
         rtx_hit_id* __restrict__ aov, Counters* __restrict__ counters) {
@@ -1681,7 +1804,7 @@ k_trace(const Launch* __restrict__ Lp, GenCtrl* ctrl, const int gen, double* __r
                     }
                 }
                 if (fresh || L.state == LS_JOB_DONE || L.state == LS_NEED_JOB)
-                    service_lane<COUNT, FAST, (WIDE == 0 && !COUNT) ? RTX_REPLAY_CAP : 0>(Lp, oc, gen, accum, aov, L, inst_bits, fresh, tl);
+                    service_lane<COUNT, FAST, (WIDE == 0 && !COUNT) ? RTX_REPLAY_CAP : 0, NEST>(Lp, oc, gen, accum, aov, L, inst_bits, fresh, tl);
                 if (drained || __ballot(L.state == LS_EMPTY) == 0ull) break;
             }
             if (COUNT) { tl.clk_serv += (unsigned long long)(clock64() - c0); tl.passes++; }
@@ -1689,7 +1812,7 @@ k_trace(const Launch* __restrict__ Lp, GenCtrl* ctrl, const int gen, double* __r
         }
         if (m_trav == 0ull) break;
         const long long c1 = COUNT ? clock64() : 0;
-        const unsigned long long m_wide = traverse_steps<COUNT, WIDE>(S, wv, L, stk, inst_bits, service_threshold, !drained, wide_lanes, wide_age, tl);
+        const unsigned long long m_wide = traverse_steps<COUNT, WIDE, NEST>(S, wv, L, stk, inst_bits, service_threshold, !drained, wide_lanes, wide_age, tl);
         if (!COUNT && WIDE != 0 && m_wide != 0ull) wide_jobs(S, wv, L, stk, inst_bits, m_wide);
         if (COUNT) tl.clk_trav += (unsigned long long)(clock64() - c1);
     }
