@@ -82,6 +82,11 @@ struct rtx_scene {
     DevBuf accum, rgb, aov, ctrl, counters, queue[2], hitbuf, launch, stacks, inst_bits;
     size_t inst_bits_cleared = 0;   // bytes of inst_bits known to be all zero
     int record_levels = 0;          // deepest chain of records in any BLAS or the TLAS
+    // Entering instances from the walk of the TLAS stacks a BLAS traversal on top of the walk's
+    // entries: the most entries that can need (three per record level), and whether every instance
+    // transform is affine (the pruning of such a walk relates object-space to world distances).
+    int nest_stack_need = 0;
+    bool affine_insts = true;
     ~rtx_scene() {
         for (hipEvent_t e : gen_events) (void)hipEventDestroy(e);
         if (ev0) (void)hipEventDestroy(ev0);
@@ -113,6 +118,7 @@ struct Flat {
     std::vector<Mesh> meshes;
     bool any_vn = false;
     int record_levels = 0;              // deepest chain of records (collapsed nodes + leaf) in any tree
+    int blas_levels = 0;                // ... in any BLAS
 };
 
 int push_tri(const rtx_scene_desc& d, const rtx_mesh& m, int face, Flat& F) {
@@ -201,6 +207,7 @@ int flatten_mesh(const rtx_scene_desc& d, const rtx_mesh& m, Flat& F) {
         // node at an even level, so a path crosses max_depth / 2 records)
         if (3 * (max_depth / 2) > RTX_STACK) return fail(RTX_ELIMIT, "BVH deeper than the traversal stack");
         F.record_levels = std::max(F.record_levels, max_depth / 2 + 1);
+        F.blas_levels = std::max(F.blas_levels, max_depth / 2 + 1);
     }
     // collapse two binary levels per record, records in DFS pre-order
     struct Collapse {
@@ -451,6 +458,13 @@ int build_scene(rtx_scene& sc, const rtx_scene_desc& d) {
         if ((rc = check_index(in.xform, d.n_xforms, true, "instance xform"))) return rc;
         const Mesh& bm = F.meshes[(size_t)in.base_mesh];
         o.xform = in.xform >= 0 ? in.xform : bm.xform;
+        if (o.xform >= 0) {
+            const Xform& x = xfs[(size_t)o.xform];
+            // (to rounding: an inverse computed numerically has a last row of (0, 0, 0, 1) only up to that)
+            auto near = [](double v, double want) { return std::fabs(v - want) <= 1e-12; };
+            if (!(near(x.inv[12], 0.0) && near(x.inv[13], 0.0) && near(x.inv[14], 0.0) && near(x.inv[15], 1.0) &&
+                  near(x.m[12], 0.0) && near(x.m[13], 0.0) && near(x.m[14], 0.0) && near(x.m[15], 1.0))) sc.affine_insts = false;
+        }
         if (bm.n_faces <= 0) continue;      // cannot produce a hit or touch the record
         TlasItem it;
         it.idx = i;
@@ -473,6 +487,7 @@ int build_scene(rtx_scene& sc, const rtx_scene_desc& d) {
         // the walk pushes up to three entries per record level, like a BLAS traversal
         if (3 * (tb.max_level + 1) > RTX_STACK) return fail(RTX_ELIMIT, "instance hierarchy deeper than the traversal stack");
         F.record_levels = std::max(F.record_levels, tb.max_level + 1);
+        sc.nest_stack_need = 3 * (tb.max_level + 1) + 3 * F.blas_levels;
         S.n_insts = d.n_instances;
     }
     // record indices -> keys (offsets in 128-byte units into the joint node + triangle allocation)
@@ -850,6 +865,8 @@ int render_frame(rtx_scene* sc, const rtx_camera* cam, int32_t tw, int32_t th, i
         }
         // page-locked, so the copy below is a plain DMA; the previous frame's (or attempt's) copy of the
         // block finished before that frame's final wait returned
+        // RTX_AMD_GEN_TIMING=1 (development aid): per-generation kernel times on stderr
+        static const bool gen_timing = getenv("RTX_AMD_GEN_TIMING") != nullptr;
         Launch& launch = *sc->h_launch;
         launch.S = sc->dev; launch.F = F;
         launch.S.limit_flag = &((GenCtrl*)M.ctrl)->limit;
@@ -864,8 +881,16 @@ int render_frame(rtx_scene* sc, const rtx_camera* cam, int32_t tw, int32_t th, i
         launch.service_threshold = sc->dev.n_insts >= 256 ? RTX_SERVICE_THRESHOLD_INSTANCED : RTX_SERVICE_THRESHOLD;
         // wave-wide traversal of a drained generation's last jobs: its visiting-order keys hold 26 record levels
         launch.wide_ok = (sc->record_levels <= 26 && !getenv("RTX_AMD_NO_WIDE")) ? 1u : 0u;
-        // (consistent mode enters instances from the TLAS walk; the wave-wide traversal knows one job per ray)
-        if (sc->consistent && sc->dev.n_insts > RTX_LINEAR_INSTS) launch.wide_ok = 0u;
+        // Instances entered from the walk of the TLAS, nearest first: always in consistent mode; in the
+        // default mode as a search (rtx_kernels.h, search_service) where instances are many.  The
+        // wave-wide traversal knows one job per ray, so these kernels do without it.
+        const bool nest = sc->consistent && !sc->counters_on && sc->dev.n_insts > RTX_LINEAR_INSTS && sc->affine_insts &&
+                          sc->nest_stack_need <= RTX_STACK;
+        const bool search = !sc->consistent && !sc->counters_on && sc->dev.n_insts >= RTX_SEARCH_MIN_INSTS && sc->affine_insts &&
+                            sc->nest_stack_need <= RTX_SEARCH_STACK && !getenv("RTX_AMD_NO_SEARCH");
+        if (nest || search) launch.wide_ok = 0u;
+        if (gen_timing) fprintf(stderr, "[rtx] instances %d: nearest-first walk %s (affine %d, stack need %d)\n", sc->dev.n_insts,
+                                nest ? "consistent" : search ? "search" : "off", (int)sc->affine_insts, sc->nest_stack_need);
         // ... and, in scenes that are not dominated by instance replay, of the long-running jobs of
         // every generation's drained waves (a kernel variant of its own; see k_trace)
         launch.chunk_max = sc->dev.n_insts >= 256 ? RTX_CHUNK_INSTANCED : RTX_CHUNK; launch.pad_launch = 0;
@@ -876,17 +901,15 @@ int render_frame(rtx_scene* sc, const rtx_camera* cam, int32_t tw, int32_t th, i
         HIP_TRY(hipMemsetAsync(M.ctrl, 0, ctrl_bytes, sc->stream));
         HIP_TRY(hipMemsetAsync(M.accum, 0, accum_bytes, sc->stream));
         if (sc->counters_on) HIP_TRY(hipMemsetAsync(M.counters, 0, (size_t)G * sizeof(Counters), sc->stream));
-        // RTX_AMD_GEN_TIMING=1 (development aid): per-generation kernel times on stderr
-        static const bool gen_timing = getenv("RTX_AMD_GEN_TIMING") != nullptr;
         // every generation's trace launches (main variant and the one for tiny generations) are
         // bracketed by events: rtx_stats.trace_ms is the sum of their durations
         if (sc->gen_events.size() < (size_t)2 * G + 1) return fail(RTX_EHIP, "event pool smaller than the generation count");
         std::vector<hipEvent_t>& gev = sc->gen_events;
         using TraceKernel = void (*)(const Launch*, GenCtrl*, int, double*, rtx_hit_id*, Counters*);
-        const bool nest = sc->consistent && sc->dev.n_insts > RTX_LINEAR_INSTS;
         const TraceKernel trace_main =
             sc->counters_on ? k_trace<true, 0, false>
-            : nest ? k_trace<false, 0, true, true>
+            : nest ? k_trace<false, 0, true, 1>
+            : search ? k_trace<false, 0, false, 2>
             : sc->consistent ? (launch.wide_old ? k_trace<false, 1, true> : k_trace<false, 0, true>)
                              : (launch.wide_old ? k_trace<false, 1, false> : k_trace<false, 0, false>);
         const TraceKernel trace_tiny = sc->consistent ? k_trace<false, 2, true> : k_trace<false, 2, false>;
@@ -945,6 +968,9 @@ int render_frame(rtx_scene* sc, const rtx_camera* cam, int32_t tw, int32_t th, i
                         (unsigned)c, (unsigned)(c >> 32), t_trace * 1e3, t_shade * 1e3);
             }
         }
+        if (gen_timing)
+            fprintf(stderr, "[rtx] rays handed back to the replay by the search: list full %u, k turned down %u, another triangle %u, "
+                    "not accepted %u, accepted after k %u\n", ctrl[0].pad[0], ctrl[0].pad[1], ctrl[0].pad[2], ctrl[0].pad[3], ctrl[0].pad[4]);
         bool overflow = false, limit = false;
         uint32_t peak = 0;
         for (int k = 0; k <= G; k++) {

@@ -191,6 +191,14 @@ struct Tally { unsigned node_visits, tri_tests, world_box, obj_trav, tlas_visits
 
 #define RTX_STACK 100                // BLAS traversal stack entries per lane (BVH depth <= 64)
 #define RTX_TLAS_STACK 48
+// Exact mode's search of the instances (search_service): the last entries of a lane's stack area
+// hold what the search has found -- one entry of parked state, then up to RTX_SEARCH_LIST instances
+// with a hit -- and the stack proper ends below them.  Lane::age holds the phase (low three bits),
+// SP_REPLAY (the ray is being done again the plain way) and, from bit 8, the length of the list.
+#define RTX_SEARCH_MIN_INSTS 32      // scenes with fewer instances replay them in index order
+#define RTX_SEARCH_LIST 16
+#define RTX_SEARCH_STACK (RTX_STACK - 1 - RTX_SEARCH_LIST)
+enum { SP_WALK = 0, SP_VERIFY = 1, SP_PROBE = 2, SP_REPLAY = 8 };
 #define RTX_ROW_DOUBLES 32          // one 256-byte LDS row per lane
 
 RTX_DEV unsigned lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
@@ -553,8 +561,8 @@ RTX_DEV void ray_begin(const Scene& S, Lane& L, const RecOut& out, const double 
 // up: rayHitsMesh's prologue, utils.cpp:418-494 + the root test of bvh.cpp:132), the object
 // sequence is exhausted (returns 0), or the lane has turned down CAP instance candidates in
 // this call (returns 2: call again in the next service pass).
-template <bool COUNT, bool FAST, int CAP, bool NEST>
-RTX_DEV int job_next(const Scene& S, const ObjCache& oc, Lane& L, const RecOut& out, unsigned* inst_bits, const double light_dist, Tally& tl) {
+template <bool COUNT, bool FAST, int CAP, int NEST>
+RTX_DEV int job_next(const Scene& S, const ObjCache& oc, Lane& L, const RecOut& out, unsigned* inst_bits, glob_v4i* stk, const double light_dist, Tally& tl) {
     const unsigned n_summary = rtx_summary_words(S.n_insts);
     const Slab ws = make_slab(L.o, L.d);         // world-space slab constants, once per call
     int turned_down = 0;
@@ -593,17 +601,27 @@ RTX_DEV int job_next(const Scene& S, const ObjCache& oc, Lane& L, const RecOut& 
                 // reference's own per-instance logic (world-box test against the then-current
                 // bound included).
                 L.word = INT_MAX; L.whi = -1; L.bits = 0u; L.sbits = 0u; L.sword = -1;
-                if (NEST) {
-                    // consistent mode: the walk enters the instances itself, nearest first (see
-                    // traverse_steps); word = stack base of the job inside an instance, whi = the
-                    // instance the current hit came from (-1: none, or something that is not an instance)
+                if (NEST == 1 || (NEST == 2 && !(L.age & SP_REPLAY))) {
+                    // the walk enters the instances itself, nearest first (see traverse_steps):
+                    // word = stack base of the job inside an instance, whi = the instance the
+                    // current nearest hit came from (-1: none, or something that is not an instance)
                     L.word = 0; L.whi = -1;
                     double tl_min[3] = {S.tl_min[0], S.tl_min[1], S.tl_min[2]}, tl_max[3] = {S.tl_max[0], S.tl_max[1], S.tl_max[2]};
                     double enter;
                     if (!box_enter(tl_min, tl_max, ws, enter) || !(L.t_min * 1.000001 >= enter)) return 0;
                     L.obj = -1;
                     L.is_shadow &= 1;
-                    L.age = 0;
+                    if (NEST == 2) {
+                        // exact mode's search (search_service): the record's distance is parked in the
+                        // lane's stack area, its register carries the bound the instance loop starts with
+                        v4i h; h.x = __double2loint(L.dist); h.y = __double2hiint(L.dist); h.z = 0; h.w = 0;
+                        stk[RTX_STACK - 1] = h;
+                        L.dist = L.t_min;
+                        L.sword = -1; L.sbits = 0x7FFFFFFFu;
+                        L.age = SP_WALK;
+                    } else {
+                        L.age = 0;
+                    }
                     L.orig_t_min = L.t_min;
                     L.ro = L.o; L.rd = L.d; L.ix = ws.ix; L.iy = ws.iy; L.iz = ws.iz; L.par = ws.par;
                     L.cur_ref = S.tl_key; L.cur_cnt = 0; L.sp = 0; L.btri = -1;
@@ -619,7 +637,7 @@ RTX_DEV int job_next(const Scene& S, const ObjCache& oc, Lane& L, const RecOut& 
                     if (box_enter(tl_min, tl_max, ws, enter) && (L.t_min >= enter)) {
                         L.obj = -1;                                  // marks the job as the TLAS walk
                         L.is_shadow &= 1;
-                        if (!COUNT) L.age = 0;
+                        if (!COUNT && NEST != 2) L.age = 0;
                         L.orig_t_min = L.t_min;
                         L.ro = L.o; L.rd = L.d; L.ix = ws.ix; L.iy = ws.iy; L.iz = ws.iz; L.par = ws.par;
                         L.cur_ref = S.tl_key; L.cur_cnt = 0; L.sp = 0; L.btri = -1;
@@ -696,7 +714,7 @@ RTX_DEV int job_next(const Scene& S, const ObjCache& oc, Lane& L, const RecOut& 
         L.orig_t_min = L.t_min;
         if (FAST) L.t_min = bound;
         L.is_shadow &= 1;
-        if (!COUNT) L.age = 0;       // (steps of the job; with counters on: of the ray, for the histogram)
+        if (!COUNT && NEST != 2) L.age = 0;       // (steps of the job; with counters on: of the ray, for the histogram)
         if (FAST && L.is_shadow) {
             // consistent mode: a shadow ray's bound starts at the light's distance, so the first
             // accepted triangle of any job, transformed or not, decides it
@@ -789,7 +807,7 @@ RTX_DEV int nest_enter(const Scene& S, const ObjCache& oc, Lane& L, const int id
 // (utils.cpp:533-668), including the fields the winning triangle test wrote
 // (utils.cpp:370-381, bvh.cpp:162).  beta and gamma of the winning triangle are recomputed
 // here with the same arithmetic that accepted it (same inputs, same bits).
-template <bool FAST, bool NEST>
+template <bool FAST, int NEST>
 RTX_DEV void job_finalize(const Scene& S, const ObjCache& oc, Lane& L, const RecOut& out) {
     if (L.btri < 0) {
         if (FAST) L.t_min = L.orig_t_min;         // (a transformed job ran with the object-space bound)
@@ -889,6 +907,176 @@ RTX_DEV void job_finalize(const Scene& S, const ObjCache& oc, Lane& L, const Rec
     L.dist = wd;
     L.t_min = wd;
     L.hit = 1;
+}
+
+// ---------------------------------------------------------------------------------------
+// Exact mode, scenes with many instances: the instance loop (utils.cpp:756-790) as a search.
+//
+// The reference takes the instances in index order; instance j is *found* when its nearest
+// triangle lies at an object-space distance t_j below the bound t of that moment (the world
+// distance of the nearest accepted hit so far -- compared with an object-space distance as it
+// is), which overwrites the record's triangle fields; it is *accepted*, the record completed and
+// t lowered, when that triangle's float-rounded world distance w_j is below t as well
+// (utils.cpp:559-570).  Hence, with t0 the bound the loop starts with:
+//   * Let k be the instance of least w among those found with bound t0 (lowest index on a tie).
+//     Every instance accepted before k has w > w_k, so the bound at k's turn lies in (w_k, t0];
+//     if k's traversal ends at the same triangle under a bound just above w_k and under t0 -- the
+//     visited sets are nested and the nearest tested triangle wins, so it does under every bound
+//     between -- k is found and accepted at its turn, whatever came before, and rewrites every
+//     field an instance writes.  From then on t = w_k: nothing after k is accepted.
+//   * Of the instances after k, those found with bound w_k overwrite the triangle fields again;
+//     the last of them (highest index) leaves its values.  An instance not found under t0 is not
+//     found under w_k either, and one found under t0 at t_j >= w_k is not.
+//   * Without such a k the bound stays t0 and only the last found instance matters.
+// So the walk of the TLAS enters instances nearest first (traverse_steps, NEST), pruning with the
+// least w so far (plus a relative 1e-6: w is rounded to float, and t * |M d| is w only up to that
+// rounding), runs each entered instance under bound t0 and lists those with a hit; then k is run
+// again under the bound just above w_k (SP_VERIFY) and finalised, and the listed instances after
+// k with t_j < w_k are run under w_k, highest index first, until one is found (SP_PROBE).  Any
+// outcome the argument does not cover (the verification fails, the list is full, an instance
+// after k is accepted after all) starts the ray again with the plain replay in index order
+// (SP_REPLAY).  An instance that matters at w_k has its world box within w_k, which no pruning
+// of the walk cuts off, so it is entered and listed.
+// ---------------------------------------------------------------------------------------
+
+// rayHitsMesh's prologue for instance `idx` with the bound `bound` (utils.cpp:418-494, bvh.cpp:132).
+// 1: the traversal job is set up on top of the lane's stack; 0: the instance is turned down.
+RTX_DEV int search_enter(const Scene& S, const ObjCache& oc, Lane& L, const int idx, const double bound) {
+    const int oi = S.n_meshes + idx;
+    const Obj* ob = oc.at(S, oi);
+    double ob2[16];
+    {
+        const v2d* p2 = (const v2d*)ob->bmin;
+#pragma unroll
+        for (int k = 0; k < 7; k++) { const v2d v = p2[k]; ob2[2 * k] = v.x; ob2[2 * k + 1] = v.y; }
+    }
+    const int root_ref = __double2loint(ob2[12]), root_count = __double2hiint(ob2[12]);
+    const int flags = __double2loint(ob2[13]);
+    if (flags & OBJ_SKIP) return 0;
+    const Slab ws = make_slab(L.o, L.d);
+    V3 ro = L.o, rd = L.d;
+    if (flags & OBJ_XF) {
+        if (flags & OBJ_BOUNDS) {
+            double enter;
+            if (!box_enter(ob2 + 0, ob2 + 3, ws, enter) || !(bound >= enter)) return 0;
+        }
+        double inv[16];
+        {
+            const v2d* p1 = (const v2d*)ob->inv;
+#pragma unroll
+            for (int k = 0; k < 8; k++) { const v2d v = p1[k]; inv[2 * k] = v.x; inv[2 * k + 1] = v.y; }
+        }
+        ro = xf_point(inv, L.o);
+        rd = normalize_f32(xf_dir(inv, L.d));
+    }
+    const Slab sl = (flags & OBJ_XF) ? make_slab(ro, rd) : ws;
+    double enter;
+    if (!box_enter(ob2 + 6, ob2 + 9, sl, enter) || !(bound >= enter)) return 0;
+    L.obj = oi;
+    L.word = L.sp;
+    L.orig_t_min = L.t_min;
+    L.t_min = bound;
+    L.is_shadow &= 1;
+    L.ro = ro; L.rd = rd; L.ix = sl.ix; L.iy = sl.iy; L.iz = sl.iz; L.par = sl.par;
+    L.cur_ref = root_ref; L.cur_cnt = root_count; L.btri = -1;
+    return 1;
+}
+
+// World distance of the hit a job has found, with job_finalize's arithmetic (utils.cpp:559-566).
+RTX_DEV double found_world_distance(const Scene& S, const ObjCache& oc, const Lane& L) {
+    const Obj* ob = oc.at(S, L.obj);
+    if (!(ob->flags & OBJ_XF)) return L.t_min;
+    const RTX_GLOBAL Tri* Tg = (const RTX_GLOBAL Tri*)(S.blas + (size_t)(unsigned)L.btri * 128u);
+    double T[9];
+#pragma unroll
+    for (int k = 0; k < 3; k++) { T[k] = Tg->a[k]; T[3 + k] = Tg->e1[k]; T[6 + k] = Tg->e2[k]; }
+    double t, beta, gamma;
+    tri_test(T, L.ro, L.rd, INFINITY, S.isect_eps, t, beta, gamma);
+    const V3 a = mk(T[0], T[1], T[2]), e1 = mk(T[3], T[4], T[5]), e2 = mk(T[6], T[7], T[8]);
+    const V3 point = vadd(vadd(a, sscale(beta, e1)), sscale(gamma, e2));
+    double m[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) m[k] = ob->m[k];
+    const V3 wp = xf_point(m, point);
+    const double dx = wp.x - L.o.x, dy = wp.y - L.o.y, dz = wp.z - L.o.z;
+    return (double)sqrtf((float)(dx * dx + dy * dy + dz * dz));
+}
+
+// One service visit of a lane whose ray is in the search.  1: a job (or the walk's next pop) is
+// set up; 0: the ray is complete; 3: the ray has to be done again by the plain replay.
+RTX_DEV int search_service(const Scene& S, const ObjCache& oc, Lane& L, const RecOut& out, glob_v4i* stk, const double light_dist) {
+    int n = L.age >> 8;
+    if ((L.age & 7) == SP_WALK) {
+        bool over = true;
+        if (L.obj != -1) {
+            // an entered instance's job (bound t0) has ended
+            double best = L.orig_t_min;
+            if (L.btri >= 0) {
+                if (n >= RTX_SEARCH_LIST) return 3 + 4 * 0;
+                const int idx = L.obj - S.n_meshes;
+                const double tj = L.t_min;
+                const double wd = found_world_distance(S, oc, L);
+                v4i e; e.x = __double2loint(tj); e.y = __double2hiint(tj); e.z = idx; e.w = L.btri;
+                stk[RTX_STACK - 2 - n] = e;
+                n++;
+                if (wd < best || (wd == best && idx < L.whi)) { best = wd; L.whi = idx; L.sword = L.btri; }
+            }
+            L.t_min = best;
+            L.age = SP_WALK | (n << 8);
+            over = nest_resume(L) == 0;
+        } else if (L.cur_cnt == -2) {
+            if (search_enter(S, oc, L, L.cur_ref, L.dist)) return 1;
+            over = nest_resume(L) == 0;
+        }
+        if (!over) return 1;
+        // ---- the walk is over: L.whi is the k of the argument above (if any), L.t_min its w (else t0)
+        L.sp = 0;
+        if (L.whi >= 0) {
+            L.age = SP_VERIFY | (n << 8);
+            const double w = L.t_min;
+            if (!search_enter(S, oc, L, L.whi, __longlong_as_double(__double_as_longlong(w) + 1ll))) return 3 + 4 * 1;
+            return 1;
+        }
+        L.age = SP_PROBE | (n << 8);
+        L.obj = -1;
+    } else if ((L.age & 7) == SP_VERIFY) {
+        if (L.btri != L.sword) return 3 + 4 * 2;
+        const double w = L.orig_t_min;
+        L.orig_t_min = L.dist;                    // any bound of (w, t0] decides alike: w < it
+        job_finalize<false, 0>(S, oc, L, out);    // accepted: the record is k's, the bound its world distance
+        if (!(L.t_min == w) || L.hit == 0) return 3 + 4 * 3;
+        if (L.is_shadow && L.t_min < light_dist) return 0;       // occluded whatever is overwritten next (distances only shrink)
+        L.age = SP_PROBE | (n << 8);
+        L.obj = -1;
+    } else if (L.obj != -1) {
+        // SP_PROBE: the job of an instance after k, bound w, has ended
+        if (L.btri >= 0) {
+            const double w = L.orig_t_min;
+            job_finalize<false, 0>(S, oc, L, out);    // found, not nearer: triangle fields overwritten, bound restored
+            if (!(L.t_min == w)) return 3 + 4 * 4;
+            return 0;
+        }
+        L.t_min = L.orig_t_min;
+        L.obj = -1;
+    }
+    // ---- SP_PROBE: the listed instance of highest index after k (below the ones already tried) with t_j < w
+    while (true) {
+        int cand = -1;
+        for (int i = 0; i < n; i++) {
+            const v4i e = stk[RTX_STACK - 2 - i];
+            if (e.z > L.whi && e.z < (int)L.sbits && e.z > cand && __hiloint2double(e.y, e.x) < L.t_min) cand = e.z;
+        }
+        if (cand < 0) break;
+        L.sbits = (unsigned)cand;
+        L.sp = 0;
+        if (search_enter(S, oc, L, cand, L.t_min)) return 1;
+    }
+    if (L.whi < 0) {
+        // nothing came of the instances: the record's distance is the parked one
+        const v4i h = stk[RTX_STACK - 1];
+        L.dist = __hiloint2double(h.y, h.x);
+    }
+    return 0;
 }
 
 // utils.cpp:1089-1111
@@ -1060,9 +1248,9 @@ RTX_DEV V3 primary_direction(const Frame& F, int px, int py) {
 
 // Divergent per-lane part of a service pass.  `fresh`: the lane has just been handed a new ray
 // (L.slot / L.o / L.d / L.is_shadow set).
-template <bool COUNT, bool FAST, int CAP, bool NEST>
+template <bool COUNT, bool FAST, int CAP, int NEST>
 RTX_DEV void service_lane(const Launch* __restrict__ Lp, const ObjCache& oc, const int gen, double* __restrict__ accum,
-                          rtx_hit_id* __restrict__ aov, Lane& L, unsigned* inst_bits, const bool fresh, Tally& tl) {
+                          rtx_hit_id* __restrict__ aov, Lane& L, unsigned* inst_bits, glob_v4i* stk, const bool fresh, Tally& tl) {
     const Scene& S = Lp->S;
     const Frame& F = Lp->F;
     const Queue& qin = Lp->q[(gen + 1) & 1];
@@ -1076,10 +1264,24 @@ RTX_DEV void service_lane(const Launch* __restrict__ Lp, const ObjCache& oc, con
         ray_begin<COUNT>(S, L, out, FAST && L.is_shadow ? oc.ctx[0] : DBL_MAX, tl);
         if (COUNT) { const long long c = clock64(); tl.sec[0] += (unsigned long long)(c - c0); tl.sec[4]++; c0 = c; }
     }
-    // consistent mode with a TLAS: instances are entered from the walk itself (traverse_steps, NEST)
-    const bool nested = NEST && L.it > S.n_meshes;
+    // instances entered from the walk of the TLAS itself (traverse_steps, NEST): consistent mode, or
+    // exact mode's search
+    bool nested = NEST && L.it > S.n_meshes && !(NEST == 2 && (L.age & SP_REPLAY));
     int nest = -1;            // 0: the walk is over, 1: a job is set up, 2: a job inside an instance has ended
-    if (L.state == LS_JOB_DONE) {
+    int srch = -1;            // exact mode's search: what search_service decided
+    if (NEST == 2 && nested && L.state == LS_JOB_DONE) {
+        srch = search_service(S, oc, L, out, stk, L.is_shadow ? oc.ctx[0] : 0.0);
+        L.state = LS_NEED_JOB;
+        if ((srch & 3) == 3) {
+            atomicAdd(S.limit_flag + 1 + (srch >> 2), 1u);      // (GenCtrl::pad of the frame's first control block: tallies by cause)
+            // not covered by the search's argument: the ray again from the start, instances replayed in index order
+            ray_begin<COUNT>(S, L, out, DBL_MAX, tl);
+            L.age = SP_REPLAY;
+            L.sp = 0;
+            nested = false;
+            srch = -1;
+        }
+    } else if (L.state == LS_JOB_DONE) {
         if (nested && L.obj == -1) {
             nest = L.cur_cnt == -2 ? nest_enter(S, oc, L, L.cur_ref) : 0;
         } else if (L.obj == -1) {
@@ -1124,8 +1326,8 @@ RTX_DEV void service_lane(const Launch* __restrict__ Lp, const ObjCache& oc, con
         }
         L.bits = 0u; L.sbits = 0u; L.sword = L.whi;
     }
-    const int more = decided ? 0 : (nest == 0 || nest == 1) ? nest : nest == 2 ? nest_resume(L)
-                             : job_next<COUNT, FAST, CAP, NEST>(S, oc, L, out, inst_bits, light_dist, tl);
+    const int more = srch >= 0 ? srch : decided ? 0 : (nest == 0 || nest == 1) ? nest : nest == 2 ? nest_resume(L)
+                             : job_next<COUNT, FAST, CAP, NEST>(S, oc, L, out, inst_bits, stk, light_dist, tl);
     if (COUNT) { const long long c = clock64(); tl.sec[2] += (unsigned long long)(c - c0); tl.sec[6]++; c0 = c; }
     if (more == 1) { L.state = LS_IN_JOB; return; }
     if (more == 2) { L.state = LS_NEED_JOB; return; }          // yielded: more candidates next time
@@ -1473,7 +1675,7 @@ RTX_DEV void wide_jobs(const Scene& S, const Wave& wv, Lane& L, glob_v4i* stk, u
 // there).  After the job the service pass takes the ray back to world space and asks for the
 // walk's next entry (cur_cnt == -1: pop, nothing to fetch).  The walk prunes with the bound as it
 // shrinks, so most instances behind the first hit are never touched.
-template <bool COUNT, int WIDE, bool NEST>
+template <bool COUNT, int WIDE, int NEST>
 RTX_DEV unsigned long long traverse_steps(const Scene& S, const Wave& wv, Lane& L, glob_v4i* __restrict__ stk, unsigned* inst_bits,
                             const int service_threshold, const bool refillable, const int wide_lanes, const int wide_age, Tally& tl) {
     const unsigned lane = wv.lane;
@@ -1532,10 +1734,12 @@ RTX_DEV unsigned long long traverse_steps(const Scene& S, const Wave& wv, Lane& 
         // the walk of the TLAS in NEST mode compares with a bound a hair above the current one: an
         // instance whose hit ties with the current one (world distances are rounded to float) must
         // still be visited, because the lower instance index wins a tie whatever the visiting order
+        // (a ray that exact mode's search has handed back to the plain replay walks the TLAS the plain way)
+        const bool nl = NEST == 1 || (NEST == 2 && !(L.age & SP_REPLAY));
         double t_cmp = 0.0;
-        if (NEST) t_cmp = L.obj == -1 ? L.t_min * 1.000001 : L.t_min;
+        if (NEST) t_cmp = (nl && L.obj == -1) ? L.t_min * 1.000001 : L.t_min;
         if (in_job) {
-            L.age++;
+            if (NEST != 2) L.age++;       // (the search keeps its phase there)
             if (NEST && L.cur_cnt == -1) {
                 need_pop = true;
             } else if (!at_leaf) {
@@ -1553,8 +1757,8 @@ RTX_DEV unsigned long long traverse_steps(const Scene& S, const Wave& wv, Lane& 
                     else hit = box_enter_nopar(nd + 6 * k, nd + 6 * k + 3, sl, e);
                     c[k].e = e;
                     const bool pass = hit & ((NEST ? t_cmp : L.t_min) >= e);
-                    c[k].ok = pass & (c[k].cnt >= 0 || (NEST && c[k].cnt == -2));
-                    if (!NEST && pass && c[k].cnt == -2) {
+                    c[k].ok = pass & (c[k].cnt >= 0 || (NEST && nl && c[k].cnt == -2));
+                    if ((!NEST || !nl) && pass && c[k].cnt == -2) {
                         // TLAS walk: the slot is a mesh instance whose world box the ray can meet
                         const int w = c[k].ref >> 5;
                         atomicOr(inst_bits + n_summary + w, 1u << (c[k].ref & 31));
@@ -1584,8 +1788,8 @@ RTX_DEV unsigned long long traverse_steps(const Scene& S, const Wave& wv, Lane& 
                     const bool earlier = k == 3 ? any2 : (k == 2 ? any1 : any0);
                     // (a full stack cannot happen with trees the host has accepted; if it does, the
                     // frame is reported as failed instead of silently losing a subtree)
-                    if (c[k].ok && earlier && L.sp >= RTX_STACK) *S.limit_flag = 1u;
-                    if (c[k].ok && earlier && L.sp < RTX_STACK) {
+                    if (c[k].ok && earlier && L.sp >= (NEST == 2 ? RTX_SEARCH_STACK : RTX_STACK)) *S.limit_flag = 1u;
+                    if (c[k].ok && earlier && L.sp < (NEST == 2 ? RTX_SEARCH_STACK : RTX_STACK)) {
                         if (L.sp > 0) stk[L.sp - 1] = L.top;
                         L.top.x = __double2loint(c[k].e); L.top.y = __double2hiint(c[k].e); L.top.z = c[k].ref; L.top.w = c[k].cnt;
                         L.sp++;
@@ -1624,7 +1828,7 @@ RTX_DEV unsigned long long traverse_steps(const Scene& S, const Wave& wv, Lane& 
         const long long p0 = COUNT ? clock64() : 0;
         int base = 0;                  // entries below belong to the suspended walk
         double t_pop = 0.0;            // (the leaf tests may have pulled the bound in)
-        if (NEST) { base = L.obj != -1 ? L.word : 0; t_pop = L.obj == -1 ? L.t_min * 1.000001 : L.t_min; }
+        if (NEST) { base = (nl && L.obj != -1) ? L.word : 0; t_pop = (nl && L.obj == -1) ? L.t_min * 1.000001 : L.t_min; }
         if (need_pop) {
             L.state = LS_JOB_DONE;
             if (L.sp > (NEST ? base : 0)) {
@@ -1687,7 +1891,7 @@ RTX_DEV unsigned long long traverse_steps(const Scene& S, const Wave& wv, Lane& 
 // WIDE = 0: main variant without any of it.  (Variants rather than branches: the mere presence
 // of the call changes the register allocation of the code around it -- the service passes pay
 // for it, which scenes dominated by instance replay notice -- so the host picks per scene.)
-template <bool COUNT, int WIDE, bool FAST, bool NEST = false>
+template <bool COUNT, int WIDE, bool FAST, int NEST = 0>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RTX_TRACE_WAVES, RTX_TRACE_WAVES)))
 k_trace(const Launch* __restrict__ Lp, GenCtrl* ctrl, const int gen, double* __restrict__ accum,
         rtx_hit_id* __restrict__ aov, Counters* __restrict__ counters) {
@@ -1804,7 +2008,7 @@ k_trace(const Launch* __restrict__ Lp, GenCtrl* ctrl, const int gen, double* __r
                     }
                 }
                 if (fresh || L.state == LS_JOB_DONE || L.state == LS_NEED_JOB)
-                    service_lane<COUNT, FAST, (WIDE == 0 && !COUNT) ? RTX_REPLAY_CAP : 0, NEST>(Lp, oc, gen, accum, aov, L, inst_bits, fresh, tl);
+                    service_lane<COUNT, FAST, (WIDE == 0 && !COUNT) ? RTX_REPLAY_CAP : 0, NEST>(Lp, oc, gen, accum, aov, L, inst_bits, stk, fresh, tl);
                 if (drained || __ballot(L.state == LS_EMPTY) == 0ull) break;
             }
             if (COUNT) { tl.clk_serv += (unsigned long long)(clock64() - c0); tl.passes++; }
