@@ -971,6 +971,10 @@ int render_frame(rtx_scene* sc, const rtx_camera* cam, int32_t tw, int32_t th, i
         if (gen_timing)
             fprintf(stderr, "[rtx] rays handed back to the replay by the search: list full %u, k turned down %u, another triangle %u, "
                     "not accepted %u, accepted after k %u\n", ctrl[0].pad[0], ctrl[0].pad[1], ctrl[0].pad[2], ctrl[0].pad[3], ctrl[0].pad[4]);
+        if (gen_timing && RTX_SEARCH_TALLY)
+            fprintf(stderr, "[rtx] search: instance jobs ended %u (with a hit %u), instances met by the walk %u, walks ended %u (with a k %u), "
+                    "probe jobs ended %u (found %u), probes tried %u\n", ctrl[0].pad[8], ctrl[0].pad[9], ctrl[0].pad[10], ctrl[0].pad[11],
+                    ctrl[0].pad[12], ctrl[0].pad[13], ctrl[0].pad[14], ctrl[0].pad[15]);
         bool overflow = false, limit = false;
         uint32_t peak = 0;
         for (int k = 0; k <= G; k++) {

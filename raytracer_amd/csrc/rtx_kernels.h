@@ -279,13 +279,17 @@ RTX_DEV void coop_fetch(const Wave& wv, int key, const char* __restrict__ blas) 
 }
 
 // Read pieces FIRST .. FIRST+N-1 of this lane's row (undoing the swizzle) into out[0 .. 2N).
+// The rows are 256-byte aligned, so the address of piece p is (row | swizzle << 4) ^ (p << 4): one
+// XOR per read from a single register.  That register is made opaque on every call: otherwise the
+// sixteen addresses, invariant across the traversal loop, are hoisted out of it and held in (or
+// spilled from) sixteen registers for the whole kernel.
 template <int FIRST, int N>
 RTX_DEV void row_read(const Wave& wv, double* out) {
-    const lds_v2d* r2 = (const lds_v2d*)(wv.rows + wv.lane * RTX_ROW_DOUBLES);
-    const unsigned sw = wv.lane & 15u;
+    unsigned at = ((unsigned)(size_t)wv.rows + wv.lane * (RTX_ROW_DOUBLES * 8u)) | ((wv.lane & 15u) << 4);
+    asm volatile("" : "+v"(at));
 #pragma unroll
     for (int p = 0; p < N; p++) {
-        const v2d v = r2[(unsigned)(FIRST + p) ^ sw];
+        const v2d v = *(const lds_v2d*)(size_t)(at ^ ((unsigned)(FIRST + p) << 4));
         out[2 * p] = v.x; out[2 * p + 1] = v.y;
     }
 }
@@ -1004,6 +1008,10 @@ RTX_DEV double found_world_distance(const Scene& S, const ObjCache& oc, const La
 
 // One service visit of a lane whose ray is in the search.  1: a job (or the walk's next pop) is
 // set up; 0: the ray is complete; 3: the ray has to be done again by the plain replay.
+#ifndef RTX_SEARCH_TALLY
+#define RTX_SEARCH_TALLY 0          // 1 (diagnostic builds): event counts in GenCtrl::pad[8..] of the first control block
+#endif
+#define SEARCH_TALLY(k) do { if (RTX_SEARCH_TALLY) atomicAdd(S.limit_flag + 9 + (k), 1u); } while (0)
 RTX_DEV int search_service(const Scene& S, const ObjCache& oc, Lane& L, const RecOut& out, glob_v4i* stk, const double light_dist) {
     int n = L.age >> 8;
     if ((L.age & 7) == SP_WALK) {
@@ -1011,7 +1019,9 @@ RTX_DEV int search_service(const Scene& S, const ObjCache& oc, Lane& L, const Re
         if (L.obj != -1) {
             // an entered instance's job (bound t0) has ended
             double best = L.orig_t_min;
+            SEARCH_TALLY(0);
             if (L.btri >= 0) {
+                SEARCH_TALLY(1);
                 if (n >= RTX_SEARCH_LIST) return 3 + 4 * 0;
                 const int idx = L.obj - S.n_meshes;
                 const double tj = L.t_min;
@@ -1020,18 +1030,35 @@ RTX_DEV int search_service(const Scene& S, const ObjCache& oc, Lane& L, const Re
                 stk[RTX_STACK - 2 - n] = e;
                 n++;
                 if (wd < best || (wd == best && idx < L.whi)) { best = wd; L.whi = idx; L.sword = L.btri; }
+                // A shadow ray asks whether the record ends up with a hit nearer than the light
+                // (utils.cpp:1083).  An instance found under t0 with w_j below the light's distance
+                // settles that if it is also found under the bound just above w_j: at its turn the
+                // bound either is no greater than w_j already -- an accepted hit that near exists --
+                // or lies in (w_j, t0], and the instance is found and accepted; from then on every
+                // distance written to the record is smaller still.  No need for the nearest of all.
+                if (L.is_shadow && wd < light_dist && tj <= wd) {
+                    L.whi = idx; L.sword = L.btri; L.t_min = wd;
+                    L.age = SP_WALK | (n << 8);
+                    L.sp = 0;
+                    nest_resume(L);
+                    goto walk_over;
+                }
             }
             L.t_min = best;
             L.age = SP_WALK | (n << 8);
             over = nest_resume(L) == 0;
         } else if (L.cur_cnt == -2) {
+            SEARCH_TALLY(2);
             if (search_enter(S, oc, L, L.cur_ref, L.dist)) return 1;
             over = nest_resume(L) == 0;
         }
         if (!over) return 1;
+    walk_over:
         // ---- the walk is over: L.whi is the k of the argument above (if any), L.t_min its w (else t0)
         L.sp = 0;
+        SEARCH_TALLY(3);
         if (L.whi >= 0) {
+            SEARCH_TALLY(4);
             L.age = SP_VERIFY | (n << 8);
             const double w = L.t_min;
             if (!search_enter(S, oc, L, L.whi, __longlong_as_double(__double_as_longlong(w) + 1ll))) return 3 + 4 * 1;
@@ -1050,7 +1077,9 @@ RTX_DEV int search_service(const Scene& S, const ObjCache& oc, Lane& L, const Re
         L.obj = -1;
     } else if (L.obj != -1) {
         // SP_PROBE: the job of an instance after k, bound w, has ended
+        SEARCH_TALLY(5);
         if (L.btri >= 0) {
+            SEARCH_TALLY(6);
             const double w = L.orig_t_min;
             job_finalize<false, 0>(S, oc, L, out);    // found, not nearer: triangle fields overwritten, bound restored
             if (!(L.t_min == w)) return 3 + 4 * 4;
@@ -1069,6 +1098,7 @@ RTX_DEV int search_service(const Scene& S, const ObjCache& oc, Lane& L, const Re
         if (cand < 0) break;
         L.sbits = (unsigned)cand;
         L.sp = 0;
+        SEARCH_TALLY(7);
         if (search_enter(S, oc, L, cand, L.t_min)) return 1;
     }
     if (L.whi < 0) {
@@ -1898,7 +1928,7 @@ k_trace(const Launch* __restrict__ Lp, GenCtrl* ctrl, const int gen, double* __r
     const Scene& S = Lp->S;
     const Frame& F = Lp->F;
     const Queue& qin = Lp->q[(gen + 1) & 1];
-    __shared__ __attribute__((aligned(16))) double lds_rows[4][64 * RTX_ROW_DOUBLES];      // 64 KB per block
+    __shared__ __attribute__((aligned(256))) double lds_rows[4][64 * RTX_ROW_DOUBLES];     // 64 KB per block
     Wave wv;
     // (wave-uniform by construction; saying so keeps the LDS-DMA destinations in scalar registers)
     wv.rows = (lds_double*)(size_t)__builtin_amdgcn_readfirstlane((int)(size_t)(lds_double*)&lds_rows[threadIdx.x >> 6][0]);
