@@ -527,15 +527,18 @@ UNIT_SCENES = {
 }
 
 
-def scene_random(out_dir, seed, res=(56, 40), detail=1):
+def scene_random(out_dir, seed, res=(56, 40), detail=1, crowd=0):
     """Seeded random scene for fuzzing the hot path against its checkers: a ground quad, 1-4
     small bumpy meshes (flat or smooth, some with transforms of their own), 0-30 instances
     (of meshes and of other instances, with and without ``_resetTransform``, scales below and
     above one, mirrored ones), up to two spheres, sometimes a plane and a free triangle, 1-3
     lights, every material type, recursion depth 0-4.  ``detail`` multiplies the meshes' resolution
-    in both directions (deep trees, long traversals)."""
+    in both directions (deep trees, long traversals).  ``crowd`` appends that many more instances
+    (drawn after everything else, so the scene without them is unchanged): random transforms as
+    above, and among them exact copies of earlier instances (hits at equal distances), instances
+    without any transform (copies of their base), and chains of instances of instances."""
     rng = np.random.default_rng(10_000 + seed)
-    name = f"random_{seed:03d}" + (f"_x{detail}" if detail != 1 else "")
+    name = f"random_{seed:03d}" + (f"_x{detail}" if detail != 1 else "") + (f"_c{crowd}" if crowd else "")
     verts = [(-25.0, 0.0, 25.0), (25.0, 0.0, 25.0), (25.0, 0.0, -25.0), (-25.0, 0.0, -25.0)]
     mats = [_mat(1, (1, 1, 1), (0.55, 0.5, 0.45), (0.3, 0.3, 0.3), phong=12),
             _mat(2, (0.2, 0.2, 0.2), (0.1, 0.1, 0.1), (0.5, 0.5, 0.5), phong=80, mirror=(0.8, 0.8, 0.8), mtype="mirror"),
@@ -620,11 +623,31 @@ def scene_random(out_dir, seed, res=(56, 40), detail=1):
         next_id += 1
     lights = [_light(k + 1, (float(rng.uniform(-9, 9)), float(rng.uniform(5, 11)), float(rng.uniform(-4, 9))),
                      tuple(float(x) for x in rng.uniform(8000, 26000, size=3))) for k in range(int(rng.integers(1, 4)))]
+    depth = str(int(rng.integers(0, 5)))
+    camera = _camera((float(rng.uniform(-3, 3)), float(rng.uniform(2, 6)), float(rng.uniform(9, 13))),
+                     (0.0, 0.8, 0.0), (0, 1, 0), 42, res, name + ".png")
+    for _ in range(crowd):
+        kind = rng.random()
+        if kind < 0.12 and insts:
+            inst = dict(insts[int(rng.integers(len(insts)))])          # an exact copy: every hit ties
+            inst["_id"] = str(next_id)
+        elif kind < 0.2:
+            inst = {"_id": str(next_id), "_baseMeshId": str(int(rng.choice(base_ids))), "_resetTransform": "false"}
+        else:
+            inst = {"_id": str(next_id), "_baseMeshId": str(int(rng.choice(base_ids))),
+                    "_resetTransform": "true" if rng.random() < 0.6 else "false", "Transformations": new_transform()}
+        if rng.random() < 0.7:
+            inst["Material"] = str(int(rng.integers(1, 7)))
+        insts.append(inst)
+        if rng.random() < 0.15:
+            base_ids.append(next_id)
+        next_id += 1
+    if insts:
+        objects["MeshInstance"] = insts
     sc = {
-        "BackgroundColor": "12 18 30", "MaxRecursionDepth": str(int(rng.integers(0, 5))), "ShadowRayEpsilon": "1e-3",
+        "BackgroundColor": "12 18 30", "MaxRecursionDepth": depth, "ShadowRayEpsilon": "1e-3",
         "IntersectionTestEpsilon": "1e-6",
-        "Cameras": {"Camera": _camera((float(rng.uniform(-3, 3)), float(rng.uniform(2, 6)), float(rng.uniform(9, 13))),
-                                      (0.0, 0.8, 0.0), (0, 1, 0), 42, res, name + ".png")},
+        "Cameras": {"Camera": camera},
         "Lights": {"AmbientLight": "20 20 20", "PointLight": lights},
         "Materials": {"Material": mats},
         "Transformations": {k: v for k, v in (("Translation", trans), ("Scaling", scal), ("Rotation", rots)) if v},

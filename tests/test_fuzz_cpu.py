@@ -47,3 +47,22 @@ def test_oracle_equals_reference_on_detailed_random_scene(tmp_path, seed):
     assert np.array_equal(rgb, ck.read_rgb(prefix + ".cam0.rgb", cam.width, cam.height))
     assert len(ck.compare_hits(hits, ck.read_hits(prefix + ".cam0.hits"))) == 0
     hs.close()
+
+
+@pytest.mark.skipif(not ck.have_reference(), reason="compiled reference (oracle/_ref) not present")
+@pytest.mark.parametrize("seed", [0, 3, 7, 12, 20, 31])
+def test_oracle_equals_reference_on_crowded_random_scene(tmp_path, seed):
+    """60-150 instances on top of the random scene: copies of one another (hits at equal distances),
+    instances without a transform, scales below and above one, mirrored ones, instances of instances.
+    What the reference's instance loop leaves in the record there is what the device library's
+    nearest-first search of the instances has to reproduce (tests/test_gpu_search.py)."""
+    path = scenes.scene_random(str(tmp_path), seed, res=(64, 48), crowd=60 + 15 * (seed % 7))
+    cull = bool(seed & 1)
+    prefix = str(tmp_path / "ref")
+    ck.reference_dump(path, prefix, cull=cull)
+    hs = rt.HostScene(path, True, cull)
+    cam, _ = hs.camera(0)
+    rgb, hits, _, _ = ck.oracle_render(hs.desc, cam)
+    assert np.array_equal(rgb, ck.read_rgb(prefix + ".cam0.rgb", cam.width, cam.height)), seed
+    assert len(ck.compare_hits(hits, ck.read_hits(prefix + ".cam0.hits"))) == 0, seed
+    hs.close()

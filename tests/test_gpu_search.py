@@ -1,0 +1,68 @@
+"""Exact mode's nearest-first search of the instances (scenes with 32 instances or more) against
+the CPU restatement and against the plain replay in index order that it stands in for: crowded
+random scenes (instances that copy one another, untransformed ones, scales below and above one,
+mirrored ones, instances of instances) and the grass stand-ins.  Hit records and picture bytes must
+be equal: the search is an evaluation order, not an approximation."""
+import os
+
+import numpy as np
+import pytest
+
+import _checkers as ck
+import raytracer_amd as rt
+from raytracer_amd import scenes
+
+pytestmark = pytest.mark.gpu
+
+
+def _both_ways(ds, cam):
+    os.environ.pop("RTX_AMD_NO_SEARCH", None)
+    a = ds.render(cam, want_hits=True)
+    os.environ["RTX_AMD_NO_SEARCH"] = "1"          # (read per frame by the library: development switch)
+    try:
+        b = ds.render(cam, want_hits=True)
+    finally:
+        os.environ.pop("RTX_AMD_NO_SEARCH", None)
+    return a, b
+
+
+@pytest.mark.parametrize("seed", list(range(24)))
+def test_crowded_random_scene(tmp_path, seed):
+    path = scenes.scene_random(str(tmp_path), seed, res=(96, 72), crowd=40 + 12 * (seed % 9))
+    hs = rt.HostScene(path, True, bool(seed & 1))
+    ds = rt.DeviceScene(hs.desc, 0)
+    cam, _ = hs.camera(0)
+    (rgb, hits, _), (r_rgb, r_hits, _) = _both_ways(ds, cam)
+    assert np.array_equal(hits, r_hits) and np.array_equal(rgb, r_rgb), seed
+    o_rgb, o_hits, _, _ = ck.oracle_render(hs.desc, cam)
+    bad = ck.compare_hits(hits, o_hits, allow_src_unknown=False)
+    assert len(bad) == 0, (seed, bad[:5], hits[bad[:3]], o_hits[bad[:3]])
+    same, mx = ck.image_diff(rgb, o_rgb)
+    assert mx <= 2 and same >= 0.999, (seed, same, mx)
+    ds.close(); hs.close()
+
+
+@pytest.mark.parametrize("name", ["grass_small", "grass_many"])
+def test_grass_search_equals_replay(unit_scenes, name):
+    hs = rt.HostScene(unit_scenes[name])
+    ds = rt.DeviceScene(hs.desc, 0)
+    cam, _ = hs.camera(0)
+    (rgb, hits, _), (r_rgb, r_hits, _) = _both_ways(ds, cam)
+    assert np.array_equal(hits, r_hits) and np.array_equal(rgb, r_rgb)
+    ds.close(); hs.close()
+
+
+def test_dense_grass_at_size(tmp_path):
+    """4000 instances seen at 640x360: long walks, many overwritten records (scales up to 2.2 put
+    blades behind the nearest one in front of it by the reference's comparison)."""
+    path = scenes.scene_grass(str(tmp_path), n_instances=4000, res=(640, 360), name="grass_mid", seed=77)
+    hs = rt.HostScene(path)
+    ds = rt.DeviceScene(hs.desc, 0)
+    cam, _ = hs.camera(0)
+    (rgb, hits, _), (r_rgb, r_hits, _) = _both_ways(ds, cam)
+    assert np.array_equal(hits, r_hits) and np.array_equal(rgb, r_rgb)
+    o_rgb, o_hits, _, _ = ck.oracle_render(hs.desc, cam)
+    assert len(ck.compare_hits(hits, o_hits, allow_src_unknown=False)) == 0
+    same, mx = ck.image_diff(rgb, o_rgb)
+    assert mx <= 2 and same >= 0.999, (same, mx)
+    ds.close(); hs.close()
