@@ -78,7 +78,7 @@ struct rtx_scene {
     bool consistent = false;
     int64_t queue_limit = (int64_t)32 << 30;
     uint32_t queue_capacity = 0;    // rays per queue, grows on overflow and is then kept
-    DevBuf materials, lights, xforms, planes, spheres, ftris, meshes, insts, objs, blas, tri_vn;
+    DevBuf materials, lights, xforms, planes, spheres, ftris, meshes, insts, blas, tri_vn;
     DevBuf accum, rgb, aov, ctrl, counters, queue[2], hitbuf, launch, stacks, inst_bits;
     size_t inst_bits_cleared = 0;   // bytes of inst_bits known to be all zero
     int record_levels = 0;          // deepest chain of records in any BLAS or the TLAS
@@ -523,7 +523,6 @@ int build_scene(rtx_scene& sc, const rtx_scene_desc& d) {
     for (int i = 0; i < d.n_meshes; i++) fill_obj(objs[(size_t)i], i, F.meshes[(size_t)i].xform, F.meshes[(size_t)i].material);
     for (int i = 0; i < d.n_instances; i++)
         fill_obj(objs[(size_t)d.n_meshes + (size_t)i], insts[(size_t)i].base_mesh, insts[(size_t)i].xform, insts[(size_t)i].material);
-    HIP_TRY(sc.objs.upload(objs));        S.objs = (const Obj*)sc.objs.p;
 
     HIP_TRY(sc.materials.upload(mats));   S.materials = (const Material*)sc.materials.p;
     HIP_TRY(sc.lights.upload(lights));    S.lights = (const Light*)sc.lights.p;
@@ -534,11 +533,16 @@ int build_scene(rtx_scene& sc, const rtx_scene_desc& d) {
     HIP_TRY(sc.meshes.upload(F.meshes));  S.meshes = (const Mesh*)sc.meshes.p;
     HIP_TRY(sc.insts.upload(insts));      S.insts = (const Inst*)sc.insts.p;
     {
-        const size_t nb = F.nodes.size() * sizeof(Node4), tb = F.tris.size() * sizeof(Tri);
-        HIP_TRY(sc.blas.ensure(nb + tb));
+        // (the object records share the allocation so that the traversal's record fetch reaches them)
+        const size_t nb = F.nodes.size() * sizeof(Node4), tb = F.tris.size() * sizeof(Tri), ob = objs.size() * sizeof(Obj);
+        if ((nb + tb + ob) / 128 > (size_t)INT_MAX) return fail(RTX_ELIMIT, "BLAS larger than 256 GB");
+        HIP_TRY(sc.blas.ensure(std::max<size_t>(nb + tb + ob, 16)));
         if (nb) HIP_TRY(hipMemcpy(sc.blas.p, F.nodes.data(), nb, hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy((char*)sc.blas.p + nb, F.tris.data(), tb, hipMemcpyHostToDevice));
+        if (ob) HIP_TRY(hipMemcpy((char*)sc.blas.p + nb + tb, objs.data(), ob, hipMemcpyHostToDevice));
         S.blas = (const char*)sc.blas.p;
+        S.obj_key0 = (int32_t)((nb + tb) / 128);
+        S.objs = (const Obj*)(S.blas + nb + tb);
     }
     if (F.any_vn) { HIP_TRY(sc.tri_vn.upload(F.tri_vn)); S.tri_vn = (const double*)sc.tri_vn.p; }
     else {

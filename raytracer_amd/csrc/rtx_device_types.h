@@ -119,12 +119,13 @@ struct Scene {
     const FreeTri* ftris;
     const Mesh* meshes;
     const Inst* insts;
-    const Obj* objs;          // n_meshes + n_insts records
-    // BLAS records: all Node4 records, then all Tri records, in one allocation.  A record is
-    // named by its offset in 128-byte units ("key"): node i has key 2i, triangle j has key
-    // tri_key0 + j.  Child refs in Node4 and root refs in Obj are keys.
+    const Obj* objs;          // n_meshes + n_insts records (they live at the end of the BLAS allocation)
+    // BLAS records: all Node4 records, then all Tri records, then the Obj records, in one
+    // allocation.  A record is named by its offset in 128-byte units ("key"): node i has key 2i,
+    // triangle j has key tri_key0 + j, object o has key obj_key0 + 4 o.  Child refs in Node4 and
+    // root refs in Obj are keys.
     const char* blas;
-    int32_t tri_key0, pad_blas;
+    int32_t tri_key0, obj_key0;
     const double* tri_vn;     // RTX_VN_STRIDE per triangle (vertex normals of its corners) or null
     // TLAS: Node4 records among the BLAS records (a slot with cnt == -2 is instance `ref`);
     // box of everything and key of the root record

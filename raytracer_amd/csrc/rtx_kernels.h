@@ -615,6 +615,7 @@ RTX_DEV int job_next(const Scene& S, const ObjCache& oc, Lane& L, const RecOut& 
                     if (!box_enter(tl_min, tl_max, ws, enter) || !(L.t_min * 1.000001 >= enter)) return 0;
                     L.obj = -1;
                     L.is_shadow &= 1;
+                    if (NEST == 1 && L.is_shadow) L.dist = L.t_min;      // a shadow ray's bound in world space, for the way back from an instance
                     if (NEST == 2) {
                         // exact mode's search (search_service): the record's distance is parked in the
                         // lane's stack area, its register carries the bound the instance loop starts with
@@ -1747,14 +1748,16 @@ RTX_DEV unsigned long long traverse_steps(const Scene& S, const Wave& wv, Lane& 
         const long long f0 = COUNT ? clock64() : 0;
         double rec[32];
         const bool wants = in_job && !(NEST && L.cur_cnt == -1);      // (a lane that only asks for a pop fetches nothing)
+        // NEST: a lane whose entry is an instance fetches the set-up half of that instance's object record
+        const int key = (NEST && L.cur_cnt == -2) ? S.obj_key0 + 4 * (S.n_meshes + L.cur_ref) : L.cur_ref;
         if (__popcll(m_job) <= RTX_SPARSE_LANES) {
             if (wants) {
-                const RTX_GLOBAL v2d* gp = (const RTX_GLOBAL v2d*)(blas + ((size_t)(unsigned)L.cur_ref << 7));
+                const RTX_GLOBAL v2d* gp = (const RTX_GLOBAL v2d*)(blas + ((size_t)(unsigned)key << 7));
 #pragma unroll
                 for (int p = 0; p < 16; p++) { const v2d v = gp[p]; rec[2 * p] = v.x; rec[2 * p + 1] = v.y; }
             }
         } else {
-            coop_fetch(wv, wants ? L.cur_ref : -1, blas);
+            coop_fetch(wv, wants ? key : -1, blas);
             if (wants) row_read<0, 16>(wv, rec);
             __builtin_amdgcn_wave_barrier();
         }
@@ -1772,6 +1775,53 @@ RTX_DEV unsigned long long traverse_steps(const Scene& S, const Wave& wv, Lane& 
             if (NEST != 2) L.age++;       // (the search keeps its phase there)
             if (NEST && L.cur_cnt == -1) {
                 need_pop = true;
+            } else if (NEST && L.cur_cnt == -2) {
+                // ---- an instance met by the walk: rayHitsMesh's prologue (utils.cpp:418-494) and the
+                // root test of bvh.cpp:132, from the record just fetched; the traversal of its BLAS
+                // starts on top of the walk's stack entries
+                const int oi = S.n_meshes + L.cur_ref;
+                const int root_ref = __double2loint(rec[28]), root_count = __double2hiint(rec[28]);
+                const int flags = __double2loint(rec[29]);
+                const bool shadow = L.is_shadow != 0;
+                bool enter_it = !(flags & OBJ_SKIP);
+                // exact mode's search runs the instance under the bound the instance loop starts with
+                // (parked in Lane::dist), world-box test included; consistent mode under the current bound
+                double bound = NEST == 2 ? L.dist : L.t_min;
+                if (NEST == 2 && enter_it && (flags & OBJ_XF) && (flags & OBJ_BOUNDS)) {
+                    double e;
+                    enter_it = box_enter(rec + 16, rec + 19, sl, e) && (bound >= e);
+                }
+                V3 ro = L.o, rd = L.d;
+                if (enter_it && (flags & OBJ_XF)) {
+                    ro = xf_point(rec, L.o);
+                    const V3 od = xf_dir(rec, L.d);
+                    rd = normalize_f32(od);
+                    if (NEST == 1) {
+                        // the bound goes to object space with the ray; a radiance ray's gets a hair of
+                        // slack so that a hit tying with the current one is found (job_finalize)
+                        bound = L.t_min / (1.0 / (double)sqrtf((float)(od.x * od.x + od.y * od.y + od.z * od.z)));
+                        if (!shadow) bound *= 1.000001;
+                    }
+                } else if (NEST == 1 && !shadow && bound < DBL_MAX) {
+                    bound = __longlong_as_double(__double_as_longlong(bound) + 1ll);
+                }
+                if (enter_it) {
+                    const Slab os = (flags & OBJ_XF) ? make_slab(ro, rd) : sl;
+                    double e;
+                    enter_it = box_enter(rec + 22, rec + 25, os, e) && (bound >= e);
+                    if (enter_it) {
+                        L.obj = oi;
+                        L.word = L.sp;
+                        L.orig_t_min = L.t_min;
+                        L.t_min = bound;
+                        L.is_shadow &= 1;
+                        if (NEST == 1) { L.age = 0; if (shadow) { L.is_shadow = 3; L.orig_t_min = bound; } }
+                        L.ro = ro; L.rd = rd; L.ix = os.ix; L.iy = os.iy; L.iz = os.iz; L.par = os.par;
+                        sl = os;
+                        L.cur_ref = root_ref; L.cur_cnt = root_count; L.btri = -1;
+                    }
+                }
+                need_pop = !enter_it;
             } else if (!at_leaf) {
                 // ---- collapsed inner node: up to four grandchildren of a binary node ------------
                 if (COUNT) { if (L.obj == -1) tl.tlas_visits++; else tl.node_visits++; }
@@ -1859,6 +1909,21 @@ RTX_DEV unsigned long long traverse_steps(const Scene& S, const Wave& wv, Lane& 
         int base = 0;                  // entries below belong to the suspended walk
         double t_pop = 0.0;            // (the leaf tests may have pulled the bound in)
         if (NEST) { base = (nl && L.obj != -1) ? L.word : 0; t_pop = (nl && L.obj == -1) ? L.t_min * 1.000001 : L.t_min; }
+        if (NEST && need_pop && nl && L.obj != -1 && L.sp <= base && L.btri < 0 && L.it > S.n_meshes &&
+            (NEST == 1 || (L.age & 7) == SP_WALK)) {
+            // the job inside an instance has ended without a hit: the ray goes back to world space
+            // and asks for the walk's next entry -- nothing a service pass would have to do
+            L.t_min = (NEST == 1 && L.is_shadow) ? L.dist : L.orig_t_min;
+            L.obj = -1; L.word = 0;
+            L.ro = L.o; L.rd = L.d;
+            const Slab ws = make_slab(L.o, L.d);
+            L.ix = ws.ix; L.iy = ws.iy; L.iz = ws.iz; L.par = ws.par;
+            sl = ws;
+            L.is_shadow &= 1;
+            L.cur_ref = 0; L.cur_cnt = -1;
+            need_pop = L.sp <= 0;            // (with entries left the pop is next step's; without, the walk is over)
+            base = 0;
+        }
         if (need_pop) {
             L.state = LS_JOB_DONE;
             if (L.sp > (NEST ? base : 0)) {
@@ -1907,8 +1972,6 @@ RTX_DEV unsigned long long traverse_steps(const Scene& S, const Wave& wv, Lane& 
                 }
             }
         }
-        // NEST: the lane's next entry is an instance: only a service pass can enter it
-        if (NEST && L.state == LS_IN_JOB && L.cur_cnt == -2) L.state = LS_JOB_DONE;
         if (COUNT) tl.clk_pop += (unsigned long long)(clock64() - p0);
     }
     return 0ull;
