@@ -146,16 +146,20 @@ def reference_bytes(c) -> int:
             + 384 * c["transformed_hits"] + 96 * c["rays"])
 
 
-def device_bytes(st) -> int:
-    """The same frame in the device's own records, from its own counters (counters on: every
-    test of the reference is carried out): a 256-byte four-wide node record per BLAS or TLAS
-    record visit, a 128-byte triangle record per triangle test, the 128 bytes of an object
-    record that hold its world and root boxes per world-box test, the 128-byte inverse matrix
-    per ray taken to object space, 96 bytes of ray record in and 128 bytes of hit record out
-    per ray (shadow rays write no record)."""
+def device_bytes(st, record_fetches=None) -> int:
+    """A frame in the device's own records.  With `record_fetches` (rtx_stats.record_fetches of the
+    timed frames, counted by the trace kernel in every mode): 256 bytes per record the traversal
+    fetched -- collapsed nodes, triangle pairs, instance set-up records -- plus 96 bytes of ray
+    record in per queued ray and 128 bytes of hit record out per radiance ray.  Without it, the
+    same from the work counters of a counters-on frame (every test of the reference carried out):
+    256 bytes per BLAS or TLAS record visit, 128 per triangle test, world-box test and ray taken
+    to object space."""
     radiance = st["rays"] - st["shadow_rays"]
+    rays_io = 96 * (st["rays"] - st["primary_rays"]) + 128 * radiance
+    if record_fetches is not None:
+        return int(256 * record_fetches) + rays_io
     return (256 * (st["node_visits"] + st["tlas_node_visits"]) + 128 * st["tri_tests"] + 128 * st["world_box_tests"]
-            + 128 * st["object_space_traversals"] + 96 * (st["rays"] - st["primary_rays"]) + 128 * radiance)
+            + 128 * st["object_space_traversals"] + rays_io)
 
 
 # FP64 operations of the device's own arithmetic, counted from raytracer_amd/csrc/rtx_kernels.h
@@ -560,8 +564,7 @@ def measure_static(R: Rank, args, name, mode, steps, warmup, with_cpu, pipelined
         alg_source = "reference algorithm's work counts (CPU restatement, untimed pass) x reference record sizes"
     else:
         ref_scaled, ref_b, alg_source = None, None, None
-    dev_b = device_bytes(cst)
-    flops = frame_flops(cst, ref_scaled)
+    flops_counted = frame_flops(cst, ref_scaled)
 
     # ---- parity of this very frame (rank 0): device (default mode) against the checker -------
     parity = None
@@ -629,6 +632,13 @@ def measure_static(R: Rank, args, name, mode, steps, warmup, with_cpu, pipelined
     out = None
     if rank == 0:
         ms_per_step = elapsed / steps * 1e3
+        # What the timed frames fetched (the default mode may take another path than the counters-on
+        # frame: in scenes with many instances it searches them nearest first instead of replaying
+        # them in index order); the arithmetic model, built on the counters, is scaled by the same ratio.
+        rec_timed = sum(s_["record_fetches"] for s_ in stats) / max(len(stats), 1)
+        rec_counted = max(int(cst["record_fetches"]), 1)
+        dev_b = device_bytes(cst, rec_timed)
+        flops = flops_counted * (rec_timed / rec_counted)
         # Dominant kernel: k_trace, the closest-hit traversal, launched once per ray generation (two
         # variants per generation, one of which returns at once).  Every generation's launches are
         # bracketed by HIP events on the library's own stream (rtx_stats.trace_ms / trace_launches).
@@ -665,9 +675,12 @@ def measure_static(R: Rank, args, name, mode, steps, warmup, with_cpu, pipelined
             "algorithmic_bytes_per_ray": alg_b / max(rays_rank, 1),
             "reference_bytes_per_frame": ref_b, "reference_bytes_source": alg_source,
             "device_bytes_per_frame": dev_b,
-            "device_bytes_source": "device counters (counters on) x device record sizes: 256 B per BLAS/TLAS record visit, "
-                                   "128 B per triangle test, world-box test and object-space transform, 96 B per queued ray, "
-                                   "128 B per hit record",
+            "device_bytes_source": "records the trace kernel fetched in the timed frames (rtx_stats.record_fetches, counted in "
+                                   "every mode) x 256 B, + 96 B per queued ray + 128 B per hit record",
+            "record_fetches_per_frame": rec_timed,
+            "record_fetches_per_frame_counters_on": rec_counted,
+            "instance_path": ("nearest-first search with verification (identical results; rtx_kernels.h, search_service)"
+                              if rec_timed < 0.9 * rec_counted else "as with counters on"),
             "l2": {"achieved": dev_b / t_trace_frame / 1e9 if t_trace_frame > 0 else 0.0, "peak": L2_PEAK_GBS,
                    "unit": "GB/s", "frac": (dev_b / t_trace_frame / 1e9 / L2_PEAK_GBS) if t_trace_frame > 0 else 0.0,
                    "note": "device record bytes of the frame / trace time: the rate at which records leave the caches "
@@ -675,6 +688,7 @@ def measure_static(R: Rank, args, name, mode, steps, warmup, with_cpu, pipelined
             "valu": {"flops_per_frame": flops, "achieved": tflops, "unit": "TFLOP/s",
                      "fp64_peak": FP64_VALU_PEAK_TF, "frac_fp64": tflops / FP64_VALU_PEAK_TF,
                      "fp32_peak": FP32_VALU_PEAK_TF, "frac_fp32": tflops / FP32_VALU_PEAK_TF,
+                     "scaled_by_record_fetches": rec_timed / rec_counted,
                      "model": "FP64 operations of the device's own arithmetic: 100 per four-wide record visit (4 slab tests "
                               "of 25), triangle tests by the stage they reach (19 / +10 / +20 / +17), 25 per world-box "
                               "test, 53 per ray taken to object space, 150 per shaded hit, 60 per shadow ray; counts from "

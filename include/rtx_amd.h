@@ -161,6 +161,10 @@ typedef struct rtx_stats {
      * both attempts). */
     double trace_ms;
     uint32_t trace_launches, pad;
+    /* 256-byte records the traversal fetched (collapsed nodes, triangle pairs, instance set-up
+     * records; one per traversing lane and step of the trace kernel's main loop): always filled,
+     * in every mode -- the device's own count of what it moved, whatever path the rays took. */
+    uint64_t record_fetches;
 } rtx_stats;
 
 typedef struct rtx_scene rtx_scene;   /* opaque: owns the device copy of the scene */

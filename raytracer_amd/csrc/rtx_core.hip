@@ -1082,6 +1082,7 @@ int render_frame(rtx_scene* sc, const rtx_camera* cam, int32_t tw, int32_t th, i
         stats->wave_leaf_steps = ctr.leaf_steps; stats->wave_leaf_lanes = ctr.leaf_lanes;
         stats->kernel_ms = kernel_ms;
         stats->trace_ms = trace_ms; stats->trace_launches = trace_launches;
+        for (int k = 0; k <= G; k++) stats->record_fetches += sc->h_ctrl[k].records;
         stats->total_ms = std::chrono::duration<double, std::milli>(std::chrono::high_resolution_clock::now() - wall0).count();
     }
     return RTX_OK;

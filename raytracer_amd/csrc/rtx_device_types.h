@@ -186,9 +186,11 @@ struct alignas(128) SubCount { unsigned long long counts; unsigned long long pad
 // larger queues.  limit: a structural limit of the traversal was hit on the device (a lane's
 // stack or a wave's frontier was full and an entry would have been dropped); the host turns it
 // into RTX_ELIMIT instead of returning a picture.
+// records: 256-byte records the generation's trace kernel fetched (one per traversing lane and step).
 struct alignas(128) GenCtrl {
     SubCount sub[RTX_NSUB];
-    unsigned head_trace, head_shade, overflow, limit, pad[28];
+    unsigned head_trace, head_shade, overflow, limit, pad[26];
+    unsigned long long records;
 };
 
 // Everything the kernels of one frame read besides the bulk arrays, kept in device memory so

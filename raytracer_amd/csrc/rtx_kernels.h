@@ -286,7 +286,9 @@ RTX_DEV void coop_fetch(const Wave& wv, int key, const char* __restrict__ blas) 
 template <int FIRST, int N>
 RTX_DEV void row_read(const Wave& wv, double* out) {
     unsigned at = ((unsigned)(size_t)wv.rows + wv.lane * (RTX_ROW_DOUBLES * 8u)) | ((wv.lane & 15u) << 4);
+#ifndef RTX_ROW_HOIST
     asm volatile("" : "+v"(at));
+#endif
 #pragma unroll
     for (int p = 0; p < N; p++) {
         const v2d v = *(const lds_v2d*)(size_t)(at ^ ((unsigned)(FIRST + p) << 4));
@@ -1708,7 +1710,8 @@ RTX_DEV void wide_jobs(const Scene& S, const Wave& wv, Lane& L, glob_v4i* stk, u
 // shrinks, so most instances behind the first hit are never touched.
 template <bool COUNT, int WIDE, int NEST>
 RTX_DEV unsigned long long traverse_steps(const Scene& S, const Wave& wv, Lane& L, glob_v4i* __restrict__ stk, unsigned* inst_bits,
-                            const int service_threshold, const bool refillable, const int wide_lanes, const int wide_age, Tally& tl) {
+                            const int service_threshold, const bool refillable, const int wide_lanes, const int wide_age, Tally& tl,
+                            unsigned& n_records) {
     const unsigned lane = wv.lane;
     const unsigned n_summary = rtx_summary_words(S.n_insts);
     const char* const blas = S.blas;
@@ -1750,6 +1753,9 @@ RTX_DEV unsigned long long traverse_steps(const Scene& S, const Wave& wv, Lane& 
         const bool wants = in_job && !(NEST && L.cur_cnt == -1);      // (a lane that only asks for a pop fetches nothing)
         // NEST: a lane whose entry is an instance fetches the set-up half of that instance's object record
         const int key = (NEST && L.cur_cnt == -2) ? S.obj_key0 + 4 * (S.n_meshes + L.cur_ref) : L.cur_ref;
+#ifndef RTX_NO_RECORD_COUNT
+        n_records += (unsigned)__popcll(__ballot(wants));          // (wave-uniform: scalar arithmetic)
+#endif
         if (__popcll(m_job) <= RTX_SPARSE_LANES) {
             if (wants) {
                 const RTX_GLOBAL v2d* gp = (const RTX_GLOBAL v2d*)(blas + ((size_t)(unsigned)key << 7));
@@ -2020,6 +2026,7 @@ k_trace(const Launch* __restrict__ Lp, GenCtrl* ctrl, const int gen, double* __r
         ((v2d*)lds_objs)[i] = ((const RTX_GLOBAL v2d*)S.objs)[i];
     __syncthreads();
     Tally tl = {};
+    unsigned n_records = 0;                      // records this wave fetches (wave-uniform; a wave stays far below 2^32)
     const long long clk_begin = COUNT ? clock64() : 0;
 
     // Rays are claimed in chunks (one atomic per chunk per wave) and handed to lanes as they
@@ -2109,11 +2116,12 @@ k_trace(const Launch* __restrict__ Lp, GenCtrl* ctrl, const int gen, double* __r
         }
         if (m_trav == 0ull) break;
         const long long c1 = COUNT ? clock64() : 0;
-        const unsigned long long m_wide = traverse_steps<COUNT, WIDE, NEST>(S, wv, L, stk, inst_bits, service_threshold, !drained, wide_lanes, wide_age, tl);
+        const unsigned long long m_wide = traverse_steps<COUNT, WIDE, NEST>(S, wv, L, stk, inst_bits, service_threshold, !drained, wide_lanes, wide_age, tl, n_records);
         if (!COUNT && WIDE != 0 && m_wide != 0ull) wide_jobs(S, wv, L, stk, inst_bits, m_wide);
         if (COUNT) tl.clk_trav += (unsigned long long)(clock64() - c1);
     }
 
+    if (lane == 0 && n_records != 0u) atomicAdd(&me->records, (unsigned long long)n_records);
     if (COUNT && counters) {
         const bool l0 = lane == 0;
         unsigned long long v[46] = {tl.rays, tl.primary, tl.shadow, tl.secondary, tl.node_visits, tl.tri_tests,
