@@ -746,9 +746,9 @@ RTX_DEV int job_next(const Scene& S, const ObjCache& oc, Lane& L, const RecOut& 
     }
 }
 
-// Consistent mode, instance phase (see traverse_steps, NEST).  nest_resume: back to the walk of
-// the TLAS with the world-space ray; returns 1 if the walk has entries left (the lane asks for a
-// pop), 0 if the ray has seen every instance it can meet.
+// Instances entered from the walk of the TLAS (see traverse_steps, NEST), after a job that found
+// something: back to the walk with the world-space ray.  Returns 1 if the walk has entries left
+// (the lane asks for a pop), 0 if the ray has seen every instance it can meet.
 RTX_DEV int nest_resume(Lane& L) {
     const Slab ws = make_slab(L.o, L.d);
     L.obj = -1; L.word = 0;
@@ -758,58 +758,6 @@ RTX_DEV int nest_resume(Lane& L) {
     L.cur_ref = 0; L.cur_cnt = -1;
     return 1;
 }
-// nest_enter: the walk has arrived at instance `idx` (its world box passed against the current
-// bound): rayHitsMesh's prologue (utils.cpp:418-494) with the bound taken to object space, and
-// the root test of bvh.cpp:132.  Returns like nest_resume when the instance is turned down.
-RTX_DEV int nest_enter(const Scene& S, const ObjCache& oc, Lane& L, const int idx) {
-    const int oi = S.n_meshes + idx;
-    const Obj* ob = oc.at(S, oi);
-    double ob2[16];
-    {
-        const v2d* p2 = (const v2d*)ob->bmin;
-#pragma unroll
-        for (int k = 3; k < 7; k++) { const v2d v = p2[k]; ob2[2 * k] = v.x; ob2[2 * k + 1] = v.y; }
-    }
-    const int root_ref = __double2loint(ob2[12]), root_count = __double2hiint(ob2[12]);
-    const int flags = __double2loint(ob2[13]);
-    if (flags & OBJ_SKIP) return nest_resume(L);
-    V3 ro = L.o, rd = L.d;
-    double bound = L.t_min;
-    // A radiance ray's bound gets a hair of slack: a hit that ties with the current one has to be
-    // found, because the instance index decides the tie (job_finalize).  World distances of
-    // transformed hits are rounded to float, so the slack is relative there and one ulp otherwise.
-    // (A shadow ray asks for any hit in front of its light: no slack.)
-    const bool shadow = L.is_shadow != 0;
-    if (flags & OBJ_XF) {
-        double inv[16];
-        {
-            const v2d* p1 = (const v2d*)ob->inv;
-#pragma unroll
-            for (int k = 0; k < 8; k++) { const v2d v = p1[k]; inv[2 * k] = v.x; inv[2 * k + 1] = v.y; }
-        }
-        ro = xf_point(inv, L.o);
-        const V3 od = xf_dir(inv, L.d);
-        rd = normalize_f32(od);
-        bound = L.t_min / (1.0 / (double)sqrtf((float)(od.x * od.x + od.y * od.y + od.z * od.z)));
-        if (!shadow) bound *= 1.000001;
-    } else if (!shadow && bound < DBL_MAX) {
-        bound = __longlong_as_double(__double_as_longlong(bound) + 1ll);
-    }
-    const Slab sl = (flags & OBJ_XF) ? make_slab(ro, rd) : make_slab(L.o, L.d);
-    double enter;
-    if (!box_enter(ob2 + 6, ob2 + 9, sl, enter) || !(bound >= enter)) return nest_resume(L);
-    L.obj = oi;
-    L.word = L.sp;                       // the walk's entries stay below the job's
-    L.orig_t_min = L.t_min;
-    L.t_min = bound;
-    L.is_shadow &= 1;
-    L.age = 0;
-    if (L.is_shadow) { L.is_shadow = 3; L.orig_t_min = bound; }      // any accepted triangle decides a shadow ray
-    L.ro = ro; L.rd = rd; L.ix = sl.ix; L.iy = sl.iy; L.iz = sl.iz; L.par = sl.par;
-    L.cur_ref = root_ref; L.cur_cnt = root_count; L.btri = -1;
-    return 1;
-}
-
 // End of a traversal job: what rayHitsMesh does after bvh->traverse returns
 // (utils.cpp:533-668), including the fields the winning triangle test wrote
 // (utils.cpp:370-381, bvh.cpp:162).  beta and gamma of the winning triangle are recomputed
@@ -1049,10 +997,6 @@ RTX_DEV int search_service(const Scene& S, const ObjCache& oc, Lane& L, const Re
             }
             L.t_min = best;
             L.age = SP_WALK | (n << 8);
-            over = nest_resume(L) == 0;
-        } else if (L.cur_cnt == -2) {
-            SEARCH_TALLY(2);
-            if (search_enter(S, oc, L, L.cur_ref, L.dist)) return 1;
             over = nest_resume(L) == 0;
         }
         if (!over) return 1;
@@ -1316,7 +1260,7 @@ RTX_DEV void service_lane(const Launch* __restrict__ Lp, const ObjCache& oc, con
         }
     } else if (L.state == LS_JOB_DONE) {
         if (nested && L.obj == -1) {
-            nest = L.cur_cnt == -2 ? nest_enter(S, oc, L, L.cur_ref) : 0;
+            nest = 0;            // (instances are entered and, on a miss, left inside the traversal loop: the walk is over)
         } else if (L.obj == -1) {
             // end of the TLAS walk: L.word .. L.whi is the range of bitmap words it marked;
             // consumption starts in front of the first summary word that covers them
@@ -1700,14 +1644,15 @@ RTX_DEV void wide_jobs(const Scene& S, const Wave& wv, Lane& L, glob_v4i* stk, u
     }
 }
 
-// NEST (consistent mode): instances are not collected for a replay in index order; the TLAS walk
-// enters them itself, nearest first.  A TLAS slot that holds an instance is a child like any
-// other; when it becomes the lane's current entry (cur_cnt == -2) the lane leaves for a service
-// pass, which takes the ray to the instance's object space and starts the traversal of its BLAS
-// on top of the walk's stack entries (Lane::word = the stack depth the job started at; pops stop
-// there).  After the job the service pass takes the ray back to world space and asks for the
-// walk's next entry (cur_cnt == -1: pop, nothing to fetch).  The walk prunes with the bound as it
-// shrinks, so most instances behind the first hit are never touched.
+// NEST (1: consistent mode, 2: exact mode's search): instances are not collected for a replay in
+// index order; the TLAS walk enters them itself, nearest first.  A TLAS slot that holds an
+// instance is a child like any other; when it becomes the lane's current entry (cur_cnt == -2)
+// the lane's record of that step is the set-up half of the instance's object record: the ray goes
+// to object space and the traversal of the instance's BLAS starts on top of the walk's stack
+// entries (Lane::word = the stack depth the job started at; pops stop there).  A job that ends
+// without a hit takes the ray back to world space and asks for the walk's next entry
+// (cur_cnt == -1: pop, nothing to fetch); one that found something ends in a service pass.  The
+// walk prunes with the bound as it shrinks, so most instances behind the first hit are never touched.
 template <bool COUNT, int WIDE, int NEST>
 RTX_DEV unsigned long long traverse_steps(const Scene& S, const Wave& wv, Lane& L, glob_v4i* __restrict__ stk, unsigned* inst_bits,
                             const int service_threshold, const bool refillable, const int wide_lanes, const int wide_age, Tally& tl,
