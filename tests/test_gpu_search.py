@@ -26,7 +26,8 @@ def _both_ways(ds, cam):
     return a, b
 
 
-@pytest.mark.parametrize("seed", list(range(24)))
+# RTX_SEARCH_SEEDS=N widens the sweep (a soak run; the default keeps the suite short)
+@pytest.mark.parametrize("seed", list(range(int(os.environ.get("RTX_SEARCH_SEEDS", "24")))))
 def test_crowded_random_scene(tmp_path, seed):
     path = scenes.scene_random(str(tmp_path), seed, res=(96, 72), crowd=40 + 12 * (seed % 9))
     hs = rt.HostScene(path, True, bool(seed & 1))
@@ -37,6 +38,23 @@ def test_crowded_random_scene(tmp_path, seed):
     o_rgb, o_hits, _, _ = ck.oracle_render(hs.desc, cam)
     bad = ck.compare_hits(hits, o_hits, allow_src_unknown=False)
     assert len(bad) == 0, (seed, bad[:5], hits[bad[:3]], o_hits[bad[:3]])
+    same, mx = ck.image_diff(rgb, o_rgb)
+    assert mx <= 2 and same >= 0.999, (seed, same, mx)
+    ds.close(); hs.close()
+
+
+@pytest.mark.parametrize("seed", [int(x) for x in os.environ.get("RTX_SEARCH_DETAILED", "2,5,11").split(",")])
+def test_crowded_detailed_random_scene(tmp_path, seed):
+    """Meshes of several thousand faces under 100-160 instances at 224x160: deep BLAS traversals
+    inside the search, long lists of found instances."""
+    path = scenes.scene_random(str(tmp_path), seed, res=(224, 160), detail=6, crowd=100 + 10 * (seed % 7))
+    hs = rt.HostScene(path, True, bool(seed & 1))
+    ds = rt.DeviceScene(hs.desc, 0)
+    cam, _ = hs.camera(0)
+    (rgb, hits, _), (r_rgb, r_hits, _) = _both_ways(ds, cam)
+    assert np.array_equal(hits, r_hits) and np.array_equal(rgb, r_rgb), seed
+    o_rgb, o_hits, _, _ = ck.oracle_render(hs.desc, cam)
+    assert len(ck.compare_hits(hits, o_hits, allow_src_unknown=False)) == 0, seed
     same, mx = ck.image_diff(rgb, o_rgb)
     assert mx <= 2 and same >= 0.999, (seed, same, mx)
     ds.close(); hs.close()
@@ -59,8 +77,11 @@ def test_dense_grass_at_size(tmp_path):
     hs = rt.HostScene(path)
     ds = rt.DeviceScene(hs.desc, 0)
     cam, _ = hs.camera(0)
-    (rgb, hits, _), (r_rgb, r_hits, _) = _both_ways(ds, cam)
+    (rgb, hits, st), (r_rgb, r_hits, r_st) = _both_ways(ds, cam)
     assert np.array_equal(hits, r_hits) and np.array_equal(rgb, r_rgb)
+    # the search is the same picture from fewer records (rtx_stats.record_fetches is counted in every mode)
+    assert 0 < st["record_fetches"] < 0.8 * r_st["record_fetches"], (st["record_fetches"], r_st["record_fetches"])
+    assert st["rays"] == r_st["rays"]
     o_rgb, o_hits, _, _ = ck.oracle_render(hs.desc, cam)
     assert len(ck.compare_hits(hits, o_hits, allow_src_unknown=False)) == 0
     same, mx = ck.image_diff(rgb, o_rgb)
