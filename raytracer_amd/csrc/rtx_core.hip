@@ -879,10 +879,6 @@ int render_frame(rtx_scene* sc, const rtx_camera* cam, int32_t tw, int32_t th, i
         launch.hb = make_hitbuf(M.hitbuf, M.hit_capacity);
         launch.stacks = M.stacks;
         launch.inst_bits = M.inst_bits; launch.inst_words = inst_words;
-        // A service pass lasts as long as its slowest lane.  Replaying instance candidates makes
-        // that long (a chain of dependent loads per candidate), so scenes with many instances
-        // gather more lanes per pass.
-        launch.service_threshold = sc->dev.n_insts >= 256 ? RTX_SERVICE_THRESHOLD_INSTANCED : RTX_SERVICE_THRESHOLD;
         // wave-wide traversal of a drained generation's last jobs: its visiting-order keys hold 26 record levels
         launch.wide_ok = (sc->record_levels <= 26 && !getenv("RTX_AMD_NO_WIDE")) ? 1u : 0u;
         // Instances entered from the walk of the TLAS, nearest first: always in consistent mode; in the
@@ -893,11 +889,16 @@ int render_frame(rtx_scene* sc, const rtx_camera* cam, int32_t tw, int32_t th, i
         const bool search = !sc->consistent && !sc->counters_on && sc->dev.n_insts >= RTX_SEARCH_MIN_INSTS && sc->affine_insts &&
                             sc->nest_stack_need <= RTX_SEARCH_STACK && !getenv("RTX_AMD_NO_SEARCH");
         if (nest || search) launch.wide_ok = 0u;
+        // A service pass lasts as long as its slowest lane.  Replaying instance candidates makes
+        // that long (a chain of dependent loads per candidate), so scenes whose many instances are
+        // replayed gather more lanes per pass and claim rays in larger chunks.
+        const bool replay_heavy = sc->dev.n_insts >= 256 && !nest && !search;
+        launch.service_threshold = replay_heavy ? RTX_SERVICE_THRESHOLD_INSTANCED : RTX_SERVICE_THRESHOLD;
         if (gen_timing) fprintf(stderr, "[rtx] instances %d: nearest-first walk %s (affine %d, stack need %d)\n", sc->dev.n_insts,
                                 nest ? "consistent" : search ? "search" : "off", (int)sc->affine_insts, sc->nest_stack_need);
         // ... and, in scenes that are not dominated by instance replay, of the long-running jobs of
         // every generation's drained waves (a kernel variant of its own; see k_trace)
-        launch.chunk_max = sc->dev.n_insts >= 256 ? RTX_CHUNK_INSTANCED : RTX_CHUNK; launch.pad_launch = 0;
+        launch.chunk_max = replay_heavy ? RTX_CHUNK_INSTANCED : RTX_CHUNK; launch.pad_launch = 0;
         launch.wide_old = (launch.wide_ok && sc->dev.n_insts < 256 && !getenv("RTX_AMD_NO_WIDE_OLD")) ? 1u : 0u;
         HIP_TRY(hipMemcpyAsync(M.launch, &launch, sizeof launch, hipMemcpyHostToDevice, sc->stream));
         const Launch* lp = (const Launch*)M.launch;

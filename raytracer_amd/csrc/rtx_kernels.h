@@ -441,7 +441,9 @@ enum { LS_EMPTY = 0, LS_NEED_JOB = 1, LS_JOB_DONE = 2, LS_IN_JOB = 3 };
 #ifndef RTX_SERVICE_THRESHOLD
 #define RTX_SERVICE_THRESHOLD 24     // lanes waiting for service that trigger a service pass ...
 #endif
+#ifndef RTX_SERVICE_THRESHOLD_INSTANCED
 #define RTX_SERVICE_THRESHOLD_INSTANCED 36   // ... and in scenes where a pass replays many instance candidates
+#endif
 #ifndef RTX_SERVICE_REPS
 #define RTX_SERVICE_REPS 4           // rounds of a service pass: lanes whose ray ended in one round are refilled in the next
 #endif
@@ -471,6 +473,8 @@ enum { LS_EMPTY = 0, LS_NEED_JOB = 1, LS_JOB_DONE = 2, LS_IN_JOB = 3 };
 #endif
 #ifndef RTX_CHUNK
 #define RTX_CHUNK 64                 // rays a wave claims per atomic, at most ...
+#endif
+#ifndef RTX_CHUNK_INSTANCED
 #define RTX_CHUNK_INSTANCED 256       // ... and in scenes dominated by instance replay
 #endif
 #ifndef RTX_TRACE_WAVES
