@@ -87,6 +87,10 @@ struct rtx_scene {
     // transform is affine (the pruning of such a walk relates object-space to world distances).
     int nest_stack_need = 0;
     bool affine_insts = true;
+    // Exact mode's search hands a ray back to the index-order replay when its argument does not
+    // cover the ray (shrunk instances, mostly).  A scene where that happens to more than one ray in
+    // ten pays for both; from the next frame on it is rendered by the replay alone.
+    bool search_unprofitable = false;
     ~rtx_scene() {
         for (hipEvent_t e : gen_events) (void)hipEventDestroy(e);
         if (ev0) (void)hipEventDestroy(ev0);
@@ -887,7 +891,7 @@ int render_frame(rtx_scene* sc, const rtx_camera* cam, int32_t tw, int32_t th, i
         const bool nest = sc->consistent && !sc->counters_on && sc->dev.n_insts > RTX_LINEAR_INSTS && sc->affine_insts &&
                           sc->nest_stack_need <= RTX_STACK;
         const bool search = !sc->consistent && !sc->counters_on && sc->dev.n_insts >= RTX_SEARCH_MIN_INSTS && sc->affine_insts &&
-                            sc->nest_stack_need <= RTX_SEARCH_STACK && !getenv("RTX_AMD_NO_SEARCH");
+                            sc->nest_stack_need <= RTX_SEARCH_STACK && !sc->search_unprofitable && !getenv("RTX_AMD_NO_SEARCH");
         if (nest || search) launch.wide_ok = 0u;
         // A service pass lasts as long as its slowest lane.  Replaying instance candidates makes
         // that long (a chain of dependent loads per candidate), so scenes whose many instances are
@@ -972,6 +976,13 @@ int render_frame(rtx_scene* sc, const rtx_camera* cam, int32_t tw, int32_t th, i
                 fprintf(stderr, "[rtx] gen %d: radiance %u shadow %u trace %.1f us shade (+resolve) %.1f us\n", gen,
                         (unsigned)c, (unsigned)(c >> 32), t_trace * 1e3, t_shade * 1e3);
             }
+        }
+        if (search) {
+            uint64_t back = 0, rays = (uint64_t)n_items0;
+            for (int k = 0; k < 5; k++) back += ctrl[0].pad[k];
+            for (int k = 1; k <= G; k++)
+                for (const SubCount& sub : ctrl[k].sub) rays += (sub.counts & 0xFFFFFFFFull) + (sub.counts >> 32);
+            if (back * 10 > rays) sc->search_unprofitable = true;
         }
         if (gen_timing)
             fprintf(stderr, "[rtx] rays handed back to the replay by the search: list full %u, k turned down %u, another triangle %u, "

@@ -195,7 +195,9 @@ struct Tally { unsigned node_visits, tri_tests, world_box, obj_trav, tlas_visits
 // hold what the search has found -- one entry of parked state, then up to RTX_SEARCH_LIST instances
 // with a hit -- and the stack proper ends below them.  Lane::age holds the phase (low three bits),
 // SP_REPLAY (the ray is being done again the plain way) and, from bit 8, the length of the list.
+#ifndef RTX_SEARCH_MIN_INSTS
 #define RTX_SEARCH_MIN_INSTS 32      // scenes with fewer instances replay them in index order
+#endif
 #define RTX_SEARCH_LIST 16
 #define RTX_SEARCH_STACK (RTX_STACK - 1 - RTX_SEARCH_LIST)
 enum { SP_WALK = 0, SP_VERIFY = 1, SP_PROBE = 2, SP_REPLAY = 8 };
