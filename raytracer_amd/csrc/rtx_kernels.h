@@ -1963,6 +1963,8 @@ k_trace(const Launch* __restrict__ Lp, GenCtrl* ctrl, const int gen, double* __r
     unsigned n_in;
     if (gen == 0) n_in = (unsigned)F.n_items0;
     else { items.load(me, qin.sub_capacity); n_in = items.n_in; }
+    // (an empty generation -- every one after a path's last bounce -- costs its launches and nothing else)
+    if (n_in == 0u) return;
     if (!COUNT) {
         const bool tiny = Lp->wide_ok != 0 && n_in <= RTX_WIDE_MAX_RAYS;
         if (tiny != (WIDE == 2)) return;
@@ -2124,6 +2126,7 @@ k_shade(const Launch* __restrict__ Lp, GenCtrl* ctrl, const int gen, double* __r
     unsigned n_in;
     if (gen == 0) n_in = (unsigned)F.n_items0;
     else { items.load(me, qin.sub_capacity); n_in = items.n_rad; }
+    if (n_in == 0u) return;
     const unsigned my_sub = (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) & (RTX_NSUB - 1u);
 
     // Batches of 64 hits are dealt to the waves round-robin: shading cost is nearly uniform, so
