@@ -987,6 +987,13 @@ int render_frame(rtx_scene* sc, const rtx_camera* cam, int32_t tw, int32_t th, i
         if (gen_timing)
             fprintf(stderr, "[rtx] rays handed back to the replay by the search: list full %u, k turned down %u, another triangle %u, "
                     "not accepted %u, accepted after k %u\n", ctrl[0].pad[0], ctrl[0].pad[1], ctrl[0].pad[2], ctrl[0].pad[3], ctrl[0].pad[4]);
+        if (gen_timing && RTX_WAVE_TALLY)
+            for (int gen = 0; gen < G; gen++) {
+                const unsigned long long sum = *(const unsigned long long*)&ctrl[gen].pad[8], mx = *(const unsigned long long*)&ctrl[gen].pad[10];
+                const unsigned n = ctrl[gen].pad[12];
+                if (n) fprintf(stderr, "[rtx] gen %d: %u waves, mean lifetime %.1f us, longest %.1f us (at 2.4 GHz): filled %.0f %%\n", gen, n,
+                               (double)sum / n / 2400.0, (double)mx / 2400.0, 100.0 * (double)sum / n / (double)mx);
+            }
         if (gen_timing && RTX_SEARCH_TALLY)
             fprintf(stderr, "[rtx] search: instance jobs ended %u (with a hit %u), instances met by the walk %u, walks ended %u (with a k %u), "
                     "probe jobs ended %u (found %u), probes tried %u\n", ctrl[0].pad[8], ctrl[0].pad[9], ctrl[0].pad[10], ctrl[0].pad[11],

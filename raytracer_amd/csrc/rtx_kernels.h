@@ -1978,6 +1978,12 @@ k_trace(const Launch* __restrict__ Lp, GenCtrl* ctrl, const int gen, double* __r
     for (unsigned i = threadIdx.x; i < (unsigned)oc.n * (unsigned)(sizeof(Obj) / 16); i += blockDim.x)
         ((v2d*)lds_objs)[i] = ((const RTX_GLOBAL v2d*)S.objs)[i];
     __syncthreads();
+#ifndef RTX_WAVE_TALLY
+#define RTX_WAVE_TALLY 0
+#endif
+#if RTX_WAVE_TALLY
+    const long long clk_begin_all = clock64();
+#endif
     Tally tl = {};
     unsigned n_records = 0;                      // records this wave fetches (wave-uniform; a wave stays far below 2^32)
     const long long clk_begin = COUNT ? clock64() : 0;
@@ -2075,6 +2081,15 @@ k_trace(const Launch* __restrict__ Lp, GenCtrl* ctrl, const int gen, double* __r
     }
 
     if (lane == 0 && n_records != 0u) atomicAdd(&me->records, (unsigned long long)n_records);
+#if RTX_WAVE_TALLY
+    // diagnostic builds: lifetimes of this generation's waves (sum, maximum, count) in its control block's padding
+    if (lane == 0) {
+        const unsigned long long life = (unsigned long long)(clock64() - clk_begin_all);
+        atomicAdd((unsigned long long*)&me->pad[8], life);
+        atomicMax((unsigned long long*)&me->pad[10], life);
+        atomicAdd(&me->pad[12], 1u);
+    }
+#endif
     if (COUNT && counters) {
         const bool l0 = lane == 0;
         unsigned long long v[46] = {tl.rays, tl.primary, tl.shadow, tl.secondary, tl.node_visits, tl.tri_tests,
