@@ -979,25 +979,26 @@ int render_frame(rtx_scene* sc, const rtx_camera* cam, int32_t tw, int32_t th, i
         }
         if (search) {
             uint64_t back = 0, rays = (uint64_t)n_items0;
-            for (int k = 0; k < 5; k++) back += ctrl[0].pad[k];
+            for (unsigned b : ctrl[0].search_back) back += b;
             for (int k = 1; k <= G; k++)
                 for (const SubCount& sub : ctrl[k].sub) rays += (sub.counts & 0xFFFFFFFFull) + (sub.counts >> 32);
             if (back * 10 > rays) sc->search_unprofitable = true;
         }
         if (gen_timing)
             fprintf(stderr, "[rtx] rays handed back to the replay by the search: list full %u, k turned down %u, another triangle %u, "
-                    "not accepted %u, accepted after k %u\n", ctrl[0].pad[0], ctrl[0].pad[1], ctrl[0].pad[2], ctrl[0].pad[3], ctrl[0].pad[4]);
+                    "not accepted %u, accepted after k %u\n", ctrl[0].search_back[0], ctrl[0].search_back[1], ctrl[0].search_back[2],
+                    ctrl[0].search_back[3], ctrl[0].search_back[4]);
         if (gen_timing && RTX_WAVE_TALLY)
             for (int gen = 0; gen < G; gen++) {
-                const unsigned long long sum = *(const unsigned long long*)&ctrl[gen].pad[8], mx = *(const unsigned long long*)&ctrl[gen].pad[10];
-                const unsigned n = ctrl[gen].pad[12];
+                const unsigned long long sum = *(const unsigned long long*)&ctrl[gen].tally[8], mx = *(const unsigned long long*)&ctrl[gen].tally[10];
+                const unsigned n = ctrl[gen].tally[12];
                 if (n) fprintf(stderr, "[rtx] gen %d: %u waves, mean lifetime %.1f us, longest %.1f us (at 2.4 GHz): filled %.0f %%\n", gen, n,
                                (double)sum / n / 2400.0, (double)mx / 2400.0, 100.0 * (double)sum / n / (double)mx);
             }
         if (gen_timing && RTX_SEARCH_TALLY)
             fprintf(stderr, "[rtx] search: instance jobs ended %u (with a hit %u), instances met by the walk %u, walks ended %u (with a k %u), "
-                    "probe jobs ended %u (found %u), probes tried %u\n", ctrl[0].pad[8], ctrl[0].pad[9], ctrl[0].pad[10], ctrl[0].pad[11],
-                    ctrl[0].pad[12], ctrl[0].pad[13], ctrl[0].pad[14], ctrl[0].pad[15]);
+                    "probe jobs ended %u (found %u), probes tried %u\n", ctrl[0].tally[0], ctrl[0].tally[1], ctrl[0].tally[2], ctrl[0].tally[3],
+                    ctrl[0].tally[4], ctrl[0].tally[5], ctrl[0].tally[6], ctrl[0].tally[7]);
         bool overflow = false, limit = false;
         uint32_t peak = 0;
         for (int k = 0; k <= G; k++) {

@@ -133,6 +133,7 @@ struct Scene {
     int32_t tl_key, pad_tl;
     // Where the traversal reports a full stack or frontier (GenCtrl::limit of the frame's first
     // control block; set per frame).  Read only at the place that reports, so it costs no register.
+    // The other words of that block (search_back, tally) are reached from it.
     unsigned* limit_flag;
 };
 
@@ -186,12 +187,20 @@ struct alignas(128) SubCount { unsigned long long counts; unsigned long long pad
 // larger queues.  limit: a structural limit of the traversal was hit on the device (a lane's
 // stack or a wave's frontier was full and an entry would have been dropped); the host turns it
 // into RTX_ELIMIT instead of returning a picture.
-// records: 256-byte records the generation's trace kernel fetched (one per traversing lane and step).
+// search_back (first control block of a frame): rays that exact mode's search of the instances handed
+// back to the index-order replay, by cause (rtx_kernels.h, search_service); `tally`: scratch of
+// diagnostic builds.  records: 256-byte records the generation's trace kernel fetched (one per
+// traversing lane and step).
 struct alignas(128) GenCtrl {
     SubCount sub[RTX_NSUB];
-    unsigned head_trace, head_shade, overflow, limit, pad[26];
+    unsigned head_trace, head_shade, overflow, limit;
+    unsigned search_back[5];
+    unsigned pad[3];
+    unsigned tally[16];
+    unsigned pad2[2];
     unsigned long long records;
 };
+static_assert(sizeof(GenCtrl) == (RTX_NSUB + 1) * 128, "GenCtrl: the sub-queue counters and one more line");
 
 // Everything the kernels of one frame read besides the bulk arrays, kept in device memory so
 // that kernels take one pointer (scalar loads) instead of a few hundred bytes of by-value

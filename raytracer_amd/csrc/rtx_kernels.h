@@ -34,6 +34,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <float.h>
+#include <stddef.h>
 #include <limits.h>
 #include <math.h>
 #include "rtx_amd.h"
@@ -966,9 +967,9 @@ RTX_DEV double found_world_distance(const Scene& S, const ObjCache& oc, const La
 // One service visit of a lane whose ray is in the search.  1: a job (or the walk's next pop) is
 // set up; 0: the ray is complete; 3: the ray has to be done again by the plain replay.
 #ifndef RTX_SEARCH_TALLY
-#define RTX_SEARCH_TALLY 0          // 1 (diagnostic builds): event counts in GenCtrl::pad[8..] of the first control block
+#define RTX_SEARCH_TALLY 0          // 1 (diagnostic builds): event counts in GenCtrl::tally of the first control block
 #endif
-#define SEARCH_TALLY(k) do { if (RTX_SEARCH_TALLY) atomicAdd(S.limit_flag + 9 + (k), 1u); } while (0)
+#define SEARCH_TALLY(k) do { if (RTX_SEARCH_TALLY) atomicAdd(S.limit_flag + (offsetof(GenCtrl, tally) - offsetof(GenCtrl, limit)) / 4 + (k), 1u); } while (0)
 RTX_DEV int search_service(const Scene& S, const ObjCache& oc, Lane& L, const RecOut& out, glob_v4i* stk, const double light_dist) {
     int n = L.age >> 8;
     if ((L.age & 7) == SP_WALK) {
@@ -1256,7 +1257,7 @@ RTX_DEV void service_lane(const Launch* __restrict__ Lp, const ObjCache& oc, con
         srch = search_service(S, oc, L, out, stk, L.is_shadow ? oc.ctx[0] : 0.0);
         L.state = LS_NEED_JOB;
         if ((srch & 3) == 3) {
-            atomicAdd(S.limit_flag + 1 + (srch >> 2), 1u);      // (GenCtrl::pad of the frame's first control block: tallies by cause)
+            atomicAdd(S.limit_flag + (offsetof(GenCtrl, search_back) - offsetof(GenCtrl, limit)) / 4 + (srch >> 2), 1u);   // tally by cause
             // not covered by the search's argument: the ray again from the start, instances replayed in index order
             ray_begin<COUNT>(S, L, out, DBL_MAX, tl);
             L.age = SP_REPLAY;
@@ -2085,9 +2086,9 @@ k_trace(const Launch* __restrict__ Lp, GenCtrl* ctrl, const int gen, double* __r
     // diagnostic builds: lifetimes of this generation's waves (sum, maximum, count) in its control block's padding
     if (lane == 0) {
         const unsigned long long life = (unsigned long long)(clock64() - clk_begin_all);
-        atomicAdd((unsigned long long*)&me->pad[8], life);
-        atomicMax((unsigned long long*)&me->pad[10], life);
-        atomicAdd(&me->pad[12], 1u);
+        atomicAdd((unsigned long long*)&me->tally[8], life);
+        atomicMax((unsigned long long*)&me->tally[10], life);
+        atomicAdd(&me->tally[12], 1u);
     }
 #endif
     if (COUNT && counters) {
