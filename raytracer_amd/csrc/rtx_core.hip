@@ -520,6 +520,9 @@ int build_scene(rtx_scene& sc, const rtx_scene_desc& d) {
             const Xform& x = xfs[(size_t)xform];
             o.flags |= OBJ_XF;
             if (x.has_bounds) o.flags |= OBJ_BOUNDS;
+            auto near = [](double v, double want) { return std::fabs(v - want) <= 1e-12; };
+            if (near(x.inv[12], 0.0) && near(x.inv[13], 0.0) && near(x.inv[14], 0.0) && near(x.inv[15], 1.0) &&
+                near(x.m[12], 0.0) && near(x.m[13], 0.0) && near(x.m[14], 0.0) && near(x.m[15], 1.0)) o.flags |= OBJ_AFFINE;
             memcpy(o.inv, x.inv, 128); memcpy(o.m, x.m, 128); memcpy(o.nrm, x.nrm, 96);
             memcpy(o.bmin, x.bmin, 24); memcpy(o.bmax, x.bmax, 24);
         }

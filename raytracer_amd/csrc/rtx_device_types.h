@@ -72,7 +72,7 @@ struct Inst {
 // finishing a traversal job is a few wide loads from one place instead of a chain of
 // dependent lookups (instance -> mesh -> transform).  First 256 bytes: job set-up
 // (utils.cpp:418-494); second 256 bytes: what a found hit needs (utils.cpp:533-668).
-enum { OBJ_XF = 1, OBJ_BOUNDS = 2, OBJ_SKIP = 4, OBJ_SMOOTH_VN = 8 };
+enum { OBJ_XF = 1, OBJ_BOUNDS = 2, OBJ_SKIP = 4, OBJ_SMOOTH_VN = 8, OBJ_AFFINE = 16 };   // OBJ_AFFINE: last matrix rows are (0, 0, 0, 1)
 struct alignas(16) Obj {
     double inv[16];                              // world -> object (Object::inverseTransformation)
     double bmin[3], bmax[3];                     // world-space AABB (valid with OBJ_BOUNDS)

@@ -217,7 +217,7 @@ typedef __attribute__((address_space(3))) v2d lds_v2d;
 typedef __attribute__((address_space(1))) v4i glob_v4i;
 
 // Per-wave context: this wave's 64 LDS rows and the lane number.
-struct Wave { lds_double* rows; unsigned lane; };
+struct Wave { lds_double* rows; unsigned lane; lds_double* ctx; };     // ctx: the lane's five doubles of ObjCache::ctx, as an LDS address
 
 // Wave-cooperative gather of one 256-byte record per requesting lane into that lane's LDS row.
 // `key` names the record by its offset in 128-byte
@@ -728,6 +728,25 @@ RTX_DEV int job_next(const Scene& S, const ObjCache& oc, Lane& L, const RecOut& 
         L.orig_t_min = L.t_min;
         if (FAST) L.t_min = bound;
         L.is_shadow &= 1;
+        if (!FAST && !COUNT && L.is_shadow && (flags & OBJ_XF) && (flags & OBJ_AFFINE)) {
+            // A shadow ray inside a transformed object (utils.cpp:476-570 decides acceptance only at
+            // the job's end, from the float-rounded world distance of the nearest triangle).  Under
+            // an affine transform that distance is t * f up to float rounding, f the factor
+            // normalize_f32 applied to the direction, and the nearest triangle is no farther than
+            // any accepted one: an accepted t with t * f * (1 + 1e-6) below both the bound the job
+            // started with and the light's distance means the job ends with an accepted hit nearer
+            // than the light, which decides the ray (see the untransformed case below).  The
+            // threshold, rounded down to float, rides in the spare half of the context's pixel word.
+            const V3 od = xf_dir(ob->inv, L.d);
+            const double f = 1.0 / (double)sqrtf((float)(od.x * od.x + od.y * od.y + od.z * od.z));
+            const double thr = smin(L.t_min, light_dist) / (f * 1.000001);
+            float thr_f = (float)thr;
+            if ((double)thr_f > thr) thr_f = __int_as_float(__float_as_int(thr_f) - 1);       // (thr is positive)
+            if (thr_f > 0.0f && thr == thr) {
+                oc.ctx[4] = __hiloint2double(__float_as_int(thr_f), __double2loint(oc.ctx[4]));
+                L.is_shadow = 5;
+            }
+        }
         if (!COUNT && NEST != 2) L.age = 0;       // (steps of the job; with counters on: of the ray, for the histogram)
         if (FAST && L.is_shadow) {
             // consistent mode: a shadow ray's bound starts at the light's distance, so the first
@@ -1860,6 +1879,10 @@ RTX_DEV unsigned long long traverse_steps(const Scene& S, const Wave& wv, Lane& 
                 if (!COUNT && (L.is_shadow & 2) && L.btri >= 0 && L.t_min < L.orig_t_min) {
                     need_pop = true; L.sp = 0;         // occluder found: the job ends here
                 }
+                if (!COUNT && !NEST && (L.is_shadow & 4) && L.btri >= 0 &&
+                    L.t_min < (double)__int_as_float(__double2hiint(wv.ctx[4]))) {
+                    need_pop = true; L.sp = 0;         // the same inside a transformed object (job_next)
+                }
             }
         }
         __builtin_amdgcn_wave_barrier();
@@ -1976,6 +1999,7 @@ k_trace(const Launch* __restrict__ Lp, GenCtrl* ctrl, const int gen, double* __r
     oc.n = min(S.n_meshes + S.n_insts, RTX_LDS_OBJS);
     __shared__ double lds_ctx[256 * 5];
     oc.ctx = lds_ctx + threadIdx.x * 5;
+    wv.ctx = (lds_double*)(size_t)(unsigned)(size_t)(lds_double*)&lds_ctx[threadIdx.x * 5];
     for (unsigned i = threadIdx.x; i < (unsigned)oc.n * (unsigned)(sizeof(Obj) / 16); i += blockDim.x)
         ((v2d*)lds_objs)[i] = ((const RTX_GLOBAL v2d*)S.objs)[i];
     __syncthreads();
