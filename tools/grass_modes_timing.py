@@ -1,5 +1,9 @@
+#!/usr/bin/env python3
+"""Dev helper (GPU box): per-generation kernel times of grass_desert in the three ways its instances can be
+taken -- exact mode's nearest-first search, the index-order replay (RTX_AMD_NO_SEARCH=1), consistent mode.
+Usage: tools/grass_modes_timing.py   (the figures come on stderr, RTX_AMD_GEN_TIMING lines)"""
 import os, sys
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ["RTX_AMD_GEN_TIMING"] = "1"
 import bench, raytracer_amd as rt
 path, _ = bench.make_workload("grass_desert", bench.scene_cache_dir())
