@@ -448,7 +448,7 @@ enum { LS_EMPTY = 0, LS_NEED_JOB = 1, LS_JOB_DONE = 2, LS_IN_JOB = 3 };
 #define RTX_SERVICE_THRESHOLD_INSTANCED 36   // ... and in scenes where a pass replays many instance candidates
 #endif
 #ifndef RTX_SERVICE_REPS
-#define RTX_SERVICE_REPS 4           // rounds of a service pass: lanes whose ray ended in one round are refilled in the next
+#define RTX_SERVICE_REPS 2           // rounds of a service pass: lanes whose ray ended in one round are refilled in the next
 #endif
 #ifndef RTX_SPARSE_LANES
 #define RTX_SPARSE_LANES 2           // at most this many traversing lanes: load records directly
