@@ -679,8 +679,9 @@ def measure_static(R: Rank, args, name, mode, steps, warmup, with_cpu, pipelined
                                    "every mode) x 256 B, + 96 B per queued ray + 128 B per hit record",
             "record_fetches_per_frame": rec_timed,
             "record_fetches_per_frame_counters_on": rec_counted,
-            "instance_path": ("nearest-first search with verification (identical results; rtx_kernels.h, search_service)"
-                              if rec_timed < 0.9 * rec_counted else "as with counters on"),
+            "instance_path": {0: "candidates replayed in index order", 1: "nearest-first search with verification (identical "
+                              "results; rtx_kernels.h, search_service)", 2: "consistent mode's nearest-first walk"}.get(
+                                  int(stats[-1].get("instance_path", 0)), "?"),
             "l2": {"achieved": dev_b / t_trace_frame / 1e9 if t_trace_frame > 0 else 0.0, "peak": L2_PEAK_GBS,
                    "unit": "GB/s", "frac": (dev_b / t_trace_frame / 1e9 / L2_PEAK_GBS) if t_trace_frame > 0 else 0.0,
                    "note": "device record bytes of the frame / trace time: the rate at which records leave the caches "

@@ -160,7 +160,12 @@ typedef struct rtx_stats {
      * duration of its launches and their number (a frame redone after a queue overflow counts
      * both attempts). */
     double trace_ms;
-    uint32_t trace_launches, pad;
+    uint32_t trace_launches;
+    /* How the frame took the scene's mesh instances: 0 = candidates from the TLAS replayed in index
+     * order (the reference's loop, utils.cpp:756-790, without the instances its world-box test turns
+     * down); 1 = the default mode's nearest-first search with verification (scenes of 32 instances
+     * or more; same records and pictures, fewer steps); 2 = consistent mode's nearest-first walk. */
+    uint32_t instance_path;
     /* 256-byte records the traversal fetched (collapsed nodes, triangle pairs, instance set-up
      * records; one per traversing lane and step of the trace kernel's main loop): always filled,
      * in every mode -- the device's own count of what it moved, whatever path the rays took. */

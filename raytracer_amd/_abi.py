@@ -100,7 +100,7 @@ class Stats(C.Structure):
                 ("generations", C.c_uint32), ("queue_overflows", C.c_uint32),
                 ("wave_inner_steps", C.c_uint64), ("wave_inner_lanes", C.c_uint64),
                 ("wave_leaf_steps", C.c_uint64), ("wave_leaf_lanes", C.c_uint64),
-                ("trace_ms", C.c_double), ("trace_launches", C.c_uint32), ("pad", C.c_uint32),
+                ("trace_ms", C.c_double), ("trace_launches", C.c_uint32), ("instance_path", C.c_uint32),
                 ("record_fetches", C.c_uint64)]
 
     def as_dict(self):

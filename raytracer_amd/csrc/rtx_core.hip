@@ -852,7 +852,7 @@ int render_frame(rtx_scene* sc, const rtx_camera* cam, int32_t tw, int32_t th, i
     StreamGuard guard{sc->stream};
     uint32_t overflows = 0;
     float kernel_ms = 0.f, trace_ms = 0.f;
-    uint32_t trace_launches = 0;
+    uint32_t trace_launches = 0, instance_path = 0;
     const bool poison = getenv("RTX_AMD_POISON_QUEUES") != nullptr;   // test aid: queues and hit records start as 0xFF
     while (true) {
         if (!noalloc) {
@@ -896,6 +896,7 @@ int render_frame(rtx_scene* sc, const rtx_camera* cam, int32_t tw, int32_t th, i
         const bool search = !sc->consistent && !sc->counters_on && sc->dev.n_insts >= RTX_SEARCH_MIN_INSTS && sc->affine_insts &&
                             sc->nest_stack_need <= RTX_SEARCH_STACK && !sc->search_unprofitable && !getenv("RTX_AMD_NO_SEARCH");
         if (nest || search) launch.wide_ok = 0u;
+        instance_path = nest ? 2u : search ? 1u : 0u;
         // A service pass lasts as long as its slowest lane.  Replaying instance candidates makes
         // that long (a chain of dependent loads per candidate), so scenes whose many instances are
         // replayed gather more lanes per pass and claim rays in larger chunks.
@@ -1104,7 +1105,7 @@ int render_frame(rtx_scene* sc, const rtx_camera* cam, int32_t tw, int32_t th, i
         stats->wave_inner_steps = ctr.inner_steps; stats->wave_inner_lanes = ctr.inner_lanes;
         stats->wave_leaf_steps = ctr.leaf_steps; stats->wave_leaf_lanes = ctr.leaf_lanes;
         stats->kernel_ms = kernel_ms;
-        stats->trace_ms = trace_ms; stats->trace_launches = trace_launches;
+        stats->trace_ms = trace_ms; stats->trace_launches = trace_launches; stats->instance_path = instance_path;
         for (int k = 0; k <= G; k++) stats->record_fetches += sc->h_ctrl[k].records;
         stats->total_ms = std::chrono::duration<double, std::milli>(std::chrono::high_resolution_clock::now() - wall0).count();
     }

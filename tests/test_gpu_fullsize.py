@@ -95,6 +95,26 @@ def test_full_frame_matches_oracle_and_reference(workloads, name, factor):
         assert np.array_equal(o_rgb, ref_img), "the oracle's frame is the reference's, byte for byte"
 
 
+@pytest.mark.parametrize("name,factor", [("grass_desert", 5), ("marching_dragons", 2)])
+def test_consistent_mode_at_size(workloads, name, factor):
+    """Consistent mode on the instance workloads (its nearest-first walk of the instances) against
+    its own CPU checker: every primary-hit record equal, the picture to the parity bar."""
+    import os
+    hs, ds = workloads(name)
+    cam, _ = hs.camera(0)
+    view = bench.reduced_camera(cam, factor)
+    ds.set_consistent(True)
+    try:
+        rgb, hits, st = ds.render(view, want_hits=True)
+    finally:
+        ds.set_consistent(False)
+    o_rgb, o_hits, _, _ = ck.oracle_render(hs.desc, view, consistent=True, nthreads=min(16, os.cpu_count() or 1))
+    assert len(ck.compare_hits(hits, o_hits, allow_src_unknown=False)) == 0, name
+    same, mx = ck.image_diff(rgb, o_rgb)
+    assert mx <= MAX_DELTA and same >= MIN_SAME, f"{name} (consistent): {same:.5f} identical, max delta {mx}"
+    assert st["instance_path"] == (2 if name == "grass_desert" or name == "marching_dragons" else 0)
+
+
 @pytest.mark.parametrize("name,tile", [("dragon_metal", (64, 64)), ("grass_desert", (128, 72))])
 def test_full_frame_properties(workloads, name, tile):
     hs, ds = workloads(name)

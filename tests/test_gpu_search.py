@@ -87,3 +87,25 @@ def test_dense_grass_at_size(tmp_path):
     same, mx = ck.image_diff(rgb, o_rgb)
     assert mx <= 2 and same >= 0.999, (same, mx)
     ds.close(); hs.close()
+
+
+def test_a_scene_that_mostly_falls_back_is_left_to_the_replay(tmp_path):
+    """rtx_stats.instance_path: the search on the first frame; the replay from the second on when more
+    than one ray in ten fell back (here: scales on both sides of one); grass keeps the search."""
+    path = scenes.scene_random(str(tmp_path), 3, res=(96, 72), crowd=76)
+    hs = rt.HostScene(path)
+    ds = rt.DeviceScene(hs.desc, 0)
+    cam, _ = hs.camera(0)
+    first, _, st1 = ds.render(cam)
+    second, _, st2 = ds.render(cam)
+    assert st1["instance_path"] == 1 and st2["instance_path"] == 0
+    assert np.array_equal(first, second)
+    ds.set_consistent(True)
+    assert ds.render(cam)[2]["instance_path"] == 2
+    ds.close(); hs.close()
+    grass = scenes.scene_grass(str(tmp_path), n_instances=400, res=(96, 54), name="grass_path")
+    hs = rt.HostScene(grass)
+    ds = rt.DeviceScene(hs.desc, 0)
+    cam, _ = hs.camera(0)
+    assert [ds.render(cam)[2]["instance_path"] for _ in range(3)] == [1, 1, 1]
+    ds.close(); hs.close()
