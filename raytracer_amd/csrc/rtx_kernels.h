@@ -2113,6 +2113,8 @@ k_trace(const Launch* __restrict__ Lp, GenCtrl* ctrl, const int gen, double* __r
         atomicAdd((unsigned long long*)&me->tally[8], life);
         atomicMax((unsigned long long*)&me->tally[10], life);
         atomicAdd(&me->tally[12], 1u);
+        const unsigned bin = (unsigned)(life / (150ull * 2400ull));          // 150 us bins at 2.4 GHz
+        atomicAdd(&me->tally[bin < 7u ? bin : 7u], 1u);
     }
 #endif
     if (COUNT && counters) {
