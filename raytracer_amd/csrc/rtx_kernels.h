@@ -2008,6 +2008,7 @@ k_trace(const Launch* __restrict__ Lp, GenCtrl* ctrl, const int gen, double* __r
 #endif
 #if RTX_WAVE_TALLY
     const long long clk_begin_all = clock64();
+    long long clk_drained = clk_begin_all;
 #endif
     Tally tl = {};
     unsigned n_records = 0;                      // records this wave fetches (wave-uniform; a wave stays far below 2^32)
@@ -2053,7 +2054,12 @@ k_trace(const Launch* __restrict__ Lp, GenCtrl* ctrl, const int gen, double* __r
                         unsigned base = 0;
                         if (lane == 0) base = atomicAdd(&me->head_trace, chunk);
                         base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
-                        if (base >= n_in) { drained = true; chunk_next = chunk_end = 0; }
+                        if (base >= n_in) {
+                            drained = true; chunk_next = chunk_end = 0;
+#if RTX_WAVE_TALLY
+                            clk_drained = clock64();
+#endif
+                        }
                         else {
                             chunk_next = base; chunk_end = min(base + chunk, n_in);
                             const unsigned share = (n_in - chunk_end) / (2u * n_waves);
@@ -2115,6 +2121,10 @@ k_trace(const Launch* __restrict__ Lp, GenCtrl* ctrl, const int gen, double* __r
         atomicAdd(&me->tally[12], 1u);
         const unsigned bin = (unsigned)(life / (150ull * 2400ull));          // 150 us bins at 2.4 GHz
         atomicAdd(&me->tally[bin < 7u ? bin : 7u], 1u);
+        // ... and how long the wave went on after it found the queue dry (sum and maximum)
+        const unsigned long long after = (unsigned long long)(clock64() - clk_drained);
+        atomicAdd((unsigned long long*)&me->tally[14], after);
+        atomicMax(&me->tally[13], (unsigned)(after >> 8));
     }
 #endif
     if (COUNT && counters) {
