@@ -997,10 +997,10 @@ int render_frame(rtx_scene* sc, const rtx_camera* cam, int32_t tw, int32_t th, i
                 const unsigned long long sum = *(const unsigned long long*)&ctrl[gen].tally[8], mx = *(const unsigned long long*)&ctrl[gen].tally[10];
                 const unsigned n = ctrl[gen].tally[12];
                 if (n) fprintf(stderr, "[rtx] gen %d: %u waves, mean lifetime %.1f us, longest %.1f us (at 2.4 GHz): filled %.0f %%; "
-                               "waves by lifetime in 150 us bins: %u %u %u %u %u %u %u %u; after the queue ran dry: mean %.1f us, longest %.1f us\n", gen, n,
+                               "waves by lifetime in 150 us bins: %u %u %u %u %u %u %u+; longest with wide jobs side by side %.1f us; after the queue ran dry: mean %.1f us, longest %.1f us\n", gen, n,
                                (double)sum / n / 2400.0, (double)mx / 2400.0, 100.0 * (double)sum / n / (double)mx,
                                ctrl[gen].tally[0], ctrl[gen].tally[1], ctrl[gen].tally[2], ctrl[gen].tally[3], ctrl[gen].tally[4],
-                               ctrl[gen].tally[5], ctrl[gen].tally[6], ctrl[gen].tally[7],
+                               ctrl[gen].tally[5], ctrl[gen].tally[6], (double)(ctrl[gen].tally[7] & 0x7FFFFFFFu) * 256.0 / 2400.0,
                                (double)*(const unsigned long long*)&ctrl[gen].tally[14] / n / 2400.0, (double)ctrl[gen].tally[13] * 256.0 / 2400.0);
             }
         if (gen_timing && RTX_SEARCH_TALLY)

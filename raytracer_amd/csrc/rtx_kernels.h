@@ -2008,7 +2008,7 @@ k_trace(const Launch* __restrict__ Lp, GenCtrl* ctrl, const int gen, double* __r
 #endif
 #if RTX_WAVE_TALLY
     const long long clk_begin_all = clock64();
-    long long clk_drained = clk_begin_all;
+    long long clk_drained = clk_begin_all, clk_wide_saving = 0;
 #endif
     Tally tl = {};
     unsigned n_records = 0;                      // records this wave fetches (wave-uniform; a wave stays far below 2^32)
@@ -2107,7 +2107,16 @@ k_trace(const Launch* __restrict__ Lp, GenCtrl* ctrl, const int gen, double* __r
         if (m_trav == 0ull) break;
         const long long c1 = COUNT ? clock64() : 0;
         const unsigned long long m_wide = traverse_steps<COUNT, WIDE, NEST>(S, wv, L, stk, inst_bits, service_threshold, !drained, wide_lanes, wide_age, tl, n_records);
+#if RTX_WAVE_TALLY
+        const long long w0 = clock64();
+#endif
         if (!COUNT && WIDE != 0 && m_wide != 0ull) wide_jobs(S, wv, L, stk, inst_bits, m_wide);
+#if RTX_WAVE_TALLY
+        if (m_wide != 0ull) {          // what running these jobs side by side instead of one after the other could save at most
+            const long long n = __popcll(m_wide);
+            clk_wide_saving += (clock64() - w0) * (n - 1) / n;
+        }
+#endif
         if (COUNT) tl.clk_trav += (unsigned long long)(clock64() - c1);
     }
 
@@ -2120,11 +2129,13 @@ k_trace(const Launch* __restrict__ Lp, GenCtrl* ctrl, const int gen, double* __r
         atomicMax((unsigned long long*)&me->tally[10], life);
         atomicAdd(&me->tally[12], 1u);
         const unsigned bin = (unsigned)(life / (150ull * 2400ull));          // 150 us bins at 2.4 GHz
-        atomicAdd(&me->tally[bin < 7u ? bin : 7u], 1u);
+        atomicAdd(&me->tally[bin < 6u ? bin : 6u], 1u);
         // ... and how long the wave went on after it found the queue dry (sum and maximum)
         const unsigned long long after = (unsigned long long)(clock64() - clk_drained);
         atomicAdd((unsigned long long*)&me->tally[14], after);
         atomicMax(&me->tally[13], (unsigned)(after >> 8));
+        // the longest lifetime if wave-wide jobs of one wave ran side by side (tally[7], units of 256 ticks, replaces the last bin)
+        atomicMax(&me->tally[7], (unsigned)((life - (unsigned long long)clk_wide_saving) >> 8) | 0x80000000u);
     }
 #endif
     if (COUNT && counters) {
