@@ -1462,10 +1462,19 @@ RTX_DEV int wave_max_i(int v) {
     return v;
 }
 
+#ifndef RTX_WAVE_TALLY
+#define RTX_WAVE_TALLY 0
+#endif
+#if RTX_WAVE_TALLY
+    // (a clock read that the compiler does not move: the wave tally attributes time to sections)
+#define RTX_TICK() ([]() __attribute__((always_inline)) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); \
+                         const long long t_ = (long long)__builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
+                         __builtin_amdgcn_sched_barrier(0); return t_; }())
+#endif
 // What the wave needs of the owner's lane, and what it hands back.  Passed by value: the function is
 // not inlined (inlined, its registers spoil the allocation of the traversal loop around the call).
 struct WideIn { double rox, roy, roz, rdx, rdy, rdz, ix, iy, iz, t_min, stop; int par, shadow, sp, cur_ref, cur_cnt; v4i top; };
-struct WideOut { double t_min; int btri, wmin, wmax; };
+struct WideOut { double t_min; int btri, wmin, wmax, steps; unsigned t_seed, t_pop, t_load, t_rest; };
 
 __device__ __attribute__((noinline)) WideOut wide_job(const Scene& S, const Wave wv, const WideIn L, glob_v4i* stk, unsigned* inst_bits,
                                                       const int src) {
@@ -1491,6 +1500,9 @@ __device__ __attribute__((noinline)) WideOut wide_job(const Scene& S, const Wave
     const bool cull = S.cull != 0;
     const double isect_eps = S.isect_eps;
 
+#if RTX_WAVE_TALLY == 3
+    long long k0 = RTX_TICK(), k_seed = 0, k_pop = 0, k_load = 0, k_rest = 0;
+#endif
     // frontier: entry i = two 16-byte halves {enter, ref, cnt} {key, shift, -}; the owner's stack from
     // the bottom, its register-held top, and on top of everything the node it is at
     lds_v4i* F = (lds_v4i*)wv.rows;
@@ -1531,7 +1543,12 @@ __device__ __attribute__((noinline)) WideOut wide_job(const Scene& S, const Wave
     unsigned long long best_key = ~0ull;
     int best_tri = INT_MAX;
     int wmin = INT_MAX, wmax = -1;
+    int n_steps = 0;
+#if RTX_WAVE_TALLY == 3
+    { const long long k1 = RTX_TICK(); k_seed = k1 - k0; k0 = k1; }
+#endif
     while (count > 0) {
+        n_steps++;
         int W = (RTX_WIDE_CAP - 104 - count) / 4;        // room for four pushes per lane, and for a depth-first descent when it is tight
         W = W > 64 ? 64 : (W < 1 ? 1 : W);
         W = W > count ? count : W;
@@ -1547,16 +1564,25 @@ __device__ __attribute__((noinline)) WideOut wide_job(const Scene& S, const Wave
         const unsigned long long key = ((unsigned long long)(unsigned)eb.y << 32) | (unsigned)eb.x;
         const int shift = eb.z;
         double rec[32];
+#if RTX_WAVE_TALLY == 3
+        { const long long k1 = RTX_TICK(); k_pop += k1 - k0; k0 = k1; }
+#endif
         if (go) {
             const RTX_GLOBAL v2d* gp = (const RTX_GLOBAL v2d*)(blas + ((size_t)(unsigned)ref << 7));
 #pragma unroll
             for (int p = 0; p < 16; p++) { const v2d v = gp[p]; rec[2 * p] = v.x; rec[2 * p + 1] = v.y; }
         }
-        // what this lane puts back: up to four entries, farthest first
-        double pe[4]; int pr[4], pc[4], prank[4];
-        int npush = 0;
+#if RTX_WAVE_TALLY == 3
+        { const long long k1 = RTX_TICK(); k_load += k1 - k0; k0 = k1; }
+#endif
+        // What this lane puts back: up to four entries, farthest first.  (Slot k of c[] goes back if
+        // c[k].ok, behind the slots above it: fixed places, no list built at run time, which would
+        // live in memory instead of registers.)  rank_of < 0: the rest of a leaf, the key stays.
+        Cand c[4];
+        c[0].ok = c[1].ok = c[2].ok = c[3].ok = false;
+        c[0].e = c[1].e = c[2].e = c[3].e = 0.0; c[0].ref = c[1].ref = c[2].ref = c[3].ref = 0; c[0].cnt = c[1].cnt = c[2].cnt = c[3].cnt = 0;
+        bool leaf_rest = false;
         if (go && cnt == 0) {
-            Cand c[4];
 #pragma unroll
             for (int k = 0; k < 4; k++) {
                 c[k].ref = k & 1 ? __double2hiint(rec[24 + (k >> 1)]) : __double2loint(rec[24 + (k >> 1)]);
@@ -1582,10 +1608,6 @@ __device__ __attribute__((noinline)) WideOut wide_job(const Scene& S, const Wave
             const bool right_first = !(d0 >= 0.0);
             cand_swap(c[0], c[2], right_first);
             cand_swap(c[1], c[3], right_first);
-#pragma unroll
-            for (int k = 3; k >= 0; k--) {
-                if (c[k].ok) { pe[npush] = c[k].e; pr[npush] = c[k].ref; pc[npush] = c[k].cnt; prank[npush] = k; npush++; }
-            }
         } else if (go && cnt > 0) {
             const double* td = rec;
             const double* tq = rec + 16;
@@ -1607,21 +1629,24 @@ __device__ __attribute__((noinline)) WideOut wide_job(const Scene& S, const Wave
                 // the lanes working on it double with every round
                 const int rest = cnt - 2;
                 const int h = rest > 2 ? ((rest >> 1) + 1) & ~1 : rest;        // an even number of triangles first
-                pe[0] = __hiloint2double(ea.y, ea.x); pr[0] = ref + 2; pc[0] = h; prank[0] = -1; npush = 1;
-                if (rest > h) { pe[1] = pe[0]; pr[1] = ref + 2 + h; pc[1] = rest - h; prank[1] = -1; npush = 2; }
+                leaf_rest = true;
+                c[3].e = c[2].e = __hiloint2double(ea.y, ea.x);
+                c[3].ref = ref + 2; c[3].cnt = h; c[3].ok = true;
+                if (rest > h) { c[2].ref = ref + 2 + h; c[2].cnt = rest - h; c[2].ok = true; }
             }
         }
         // append: exclusive prefix of the push counts over the lanes
+        const int npush = (int)c[0].ok + (int)c[1].ok + (int)c[2].ok + (int)c[3].ok;
         int incl = npush;
         for (int off = 1; off < 64; off <<= 1) { const int o = __shfl_up(incl, off); if ((int)lane >= off) incl += o; }
         const int total = __shfl(incl, 63);
         int at = count + incl - npush;
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            if (j < npush && at < RTX_WIDE_CAP) {
-                v4i a; a.x = __double2loint(pe[j]); a.y = __double2hiint(pe[j]); a.z = pr[j]; a.w = pc[j];
+        for (int k = 3; k >= 0; k--) {
+            if (c[k].ok && at < RTX_WIDE_CAP) {
+                v4i a; a.x = __double2loint(c[k].e); a.y = __double2hiint(c[k].e); a.z = c[k].ref; a.w = c[k].cnt;
                 unsigned long long k2 = key; int sh = shift;
-                if (prank[j] >= 0) { k2 = key | ((unsigned long long)(unsigned)prank[j] << (shift > 0 ? shift : 0)); sh = shift - 2; }
+                if (!leaf_rest) { k2 = key | ((unsigned long long)(unsigned)k << (shift > 0 ? shift : 0)); sh = shift - 2; }
                 v4i bb; bb.x = (int)(unsigned)k2; bb.y = (int)(unsigned)(k2 >> 32); bb.z = sh; bb.w = 0;
                 F[2 * at] = a; F[2 * at + 1] = bb;
                 at++;
@@ -1637,6 +1662,9 @@ __device__ __attribute__((noinline)) WideOut wide_job(const Scene& S, const Wave
         __builtin_amdgcn_wave_barrier();
         const double m = wave_min_d(best_t);
         B = m < B ? m : B;
+#if RTX_WAVE_TALLY == 3
+        { const long long k1 = RTX_TICK(); k_rest += k1 - k0; k0 = k1; }
+#endif
         if (any_hit && B < stop) break;
     }
     // the winner: smallest t, then first in the reference's visiting order
@@ -1645,14 +1673,19 @@ __device__ __attribute__((noinline)) WideOut wide_job(const Scene& S, const Wave
     const int trmin = wave_min_i((best_t == tmin && best_key == kmin) ? best_tri : INT_MAX);
     const int all_wmin = wave_min_i(wmin), all_wmax = wave_max_i(wmax);
     WideOut out;
-    out.t_min = tmin; out.btri = trmin; out.wmin = all_wmin; out.wmax = all_wmax;
+    out.t_min = tmin; out.btri = trmin; out.wmin = all_wmin; out.wmax = all_wmax; out.steps = n_steps;
+    out.t_seed = out.t_pop = out.t_load = out.t_rest = 0;
+#if RTX_WAVE_TALLY == 3
+    out.t_seed = (unsigned)k_seed; out.t_pop = (unsigned)k_pop; out.t_load = (unsigned)k_load; out.t_rest = (unsigned)k_rest;
+#endif
     __builtin_amdgcn_wave_barrier();
     return out;
 }
 
 // Run the jobs of the lanes in `m` wave-wide, one after the other.
-RTX_DEV void wide_jobs(const Scene& S, const Wave& wv, Lane& L, glob_v4i* stk, unsigned* inst_bits,
-                       unsigned long long m) {
+RTX_DEV WideOut wide_jobs(const Scene& S, const Wave& wv, Lane& L, glob_v4i* stk, unsigned* inst_bits,
+                          unsigned long long m) {
+    WideOut longest = {};       // (the job of most steps: diagnostic builds report it)
     WideIn in;
     in.rox = L.ro.x; in.roy = L.ro.y; in.roz = L.ro.z; in.rdx = L.rd.x; in.rdy = L.rd.y; in.rdz = L.rd.z;
     in.ix = L.ix; in.iy = L.iy; in.iz = L.iz; in.t_min = L.t_min; in.stop = L.orig_t_min;
@@ -1661,6 +1694,7 @@ RTX_DEV void wide_jobs(const Scene& S, const Wave& wv, Lane& L, glob_v4i* stk, u
         const int src = __ffsll((long long)m) - 1;
         m &= m - 1ull;
         const WideOut out = wide_job(S, wv, in, stk, inst_bits, src);
+        if (out.steps > longest.steps) longest = out;
         if ((int)wv.lane == src) {
             if (out.t_min < INFINITY) { L.t_min = out.t_min; L.btri = out.btri; }
             L.word = min(L.word, out.wmin); L.whi = max(L.whi, out.wmax);
@@ -1668,6 +1702,7 @@ RTX_DEV void wide_jobs(const Scene& S, const Wave& wv, Lane& L, glob_v4i* stk, u
             L.state = LS_JOB_DONE;
         }
     }
+    return longest;
 }
 
 // NEST (1: consistent mode, 2: exact mode's search): instances are not collected for a replay in
@@ -1989,10 +2024,9 @@ k_trace(const Launch* __restrict__ Lp, GenCtrl* ctrl, const int gen, double* __r
     else { items.load(me, qin.sub_capacity); n_in = items.n_in; }
     // (an empty generation -- every one after a path's last bounce -- costs its launches and nothing else)
     if (n_in == 0u) return;
-    if (!COUNT) {
-        const bool tiny = Lp->wide_ok != 0 && n_in <= RTX_WIDE_MAX_RAYS;
-        if (tiny != (WIDE == 2)) return;
-    }
+    // (a kernel with the wave-wide traversal serves tiny generations itself: see wide_age below)
+    const bool tiny = !COUNT && Lp->wide_ok != 0 && n_in <= RTX_WIDE_MAX_RAYS;
+    if (!COUNT && ((WIDE == 0 && tiny) || (WIDE == 2 && !tiny))) return;
     __shared__ __attribute__((aligned(16))) double lds_objs[RTX_LDS_OBJS * (sizeof(Obj) / 8)];
     ObjCache oc;
     oc.lds = (const Obj*)lds_objs;
@@ -2003,12 +2037,11 @@ k_trace(const Launch* __restrict__ Lp, GenCtrl* ctrl, const int gen, double* __r
     for (unsigned i = threadIdx.x; i < (unsigned)oc.n * (unsigned)(sizeof(Obj) / 16); i += blockDim.x)
         ((v2d*)lds_objs)[i] = ((const RTX_GLOBAL v2d*)S.objs)[i];
     __syncthreads();
-#ifndef RTX_WAVE_TALLY
-#define RTX_WAVE_TALLY 0
-#endif
 #if RTX_WAVE_TALLY
-    const long long clk_begin_all = clock64();
-    long long clk_drained = clk_begin_all, clk_wide_saving = 0;
+    const long long clk_begin_all = RTX_TICK();
+    long long clk_drained = clk_begin_all, clk_wide_saving = 0, clk_wide = 0, clk_steps = 0, clk_service = 0, clk_lane = 0;
+    unsigned n_wide_jobs = 0, n_passes = 0;
+    WideOut wl = {};
 #endif
     Tally tl = {};
     unsigned n_records = 0;                      // records this wave fetches (wave-uniform; a wave stays far below 2^32)
@@ -2022,7 +2055,12 @@ k_trace(const Launch* __restrict__ Lp, GenCtrl* ctrl, const int gen, double* __r
     unsigned chunk = (n_in + 2u * n_waves - 1u) / (2u * n_waves);
     const unsigned chunk_max = Lp->chunk_max;
     chunk = chunk < 1u ? 1u : (chunk > chunk_max ? chunk_max : chunk);
-    unsigned chunk_next = 0, chunk_end = 0;      // wave-uniform
+    // A wave's first chunk is its share by position, without the counter: two thousand waves that
+    // start together and all ask one counter wait in line for it (tens of microseconds for the last of
+    // them, which is most of a thin generation).  The counter hands out what lies beyond those shares.
+    const unsigned static_end = n_waves * chunk;
+    unsigned chunk_next = min((blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * chunk, n_in);      // wave-uniform
+    unsigned chunk_end = min(chunk_next + chunk, n_in);
     bool drained = false;                        // wave-uniform: the generation has no rays left
 
     glob_v4i* const stk = (glob_v4i*)Lp->stacks +
@@ -2030,7 +2068,7 @@ k_trace(const Launch* __restrict__ Lp, GenCtrl* ctrl, const int gen, double* __r
     unsigned* const inst_bits = Lp->inst_bits + ((size_t)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 64u + lane) * Lp->inst_words;
     const int service_threshold = (int)Lp->service_threshold;
     const bool thin = gen != 0 && n_in < RTX_SCATTER_THIN_RAYS;
-    const int wide_lanes = thin ? RTX_WIDE_LANES_THIN : RTX_WIDE_LANES, wide_age = thin ? RTX_WIDE_AGE_THIN : RTX_WIDE_AGE;
+    const int wide_lanes = thin ? RTX_WIDE_LANES_THIN : RTX_WIDE_LANES, wide_age = tiny ? 0 : thin ? RTX_WIDE_AGE_THIN : RTX_WIDE_AGE;
     Lane L;
     L.state = LS_EMPTY; L.cur_cnt = 0; L.cur_ref = 0; L.sp = 0; L.slot = 0; L.is_shadow = 0; L.btri = -1; L.obj = 0;
     L.top = (v4i)(0); L.t_min = 0.0; L.ro = mk(0, 0, 0); L.rd = mk(0, 0, 1); L.ix = L.iy = L.iz = 0.0; L.par = 0;
@@ -2046,18 +2084,23 @@ k_trace(const Launch* __restrict__ Lp, GenCtrl* ctrl, const int gen, double* __r
         if (n_service > 0 && (m_trav == 0ull || n_service >= service_threshold)) {
             // ---- service pass ---------------------------------------------------------------
             const long long c0 = COUNT ? clock64() : 0;
+#if RTX_WAVE_TALLY
+            const long long s0 = RTX_TICK();
+#endif
             for (int rep = 0; rep < RTX_SERVICE_REPS; rep++) {
                 const unsigned long long me_ = __ballot(L.state == LS_EMPTY);
                 bool fresh = false;
                 if (me_ != 0ull && !drained) {
                     if (chunk_next == chunk_end) {
-                        unsigned base = 0;
-                        if (lane == 0) base = atomicAdd(&me->head_trace, chunk);
-                        base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
+                        unsigned base = n_in;
+                        if (static_end < n_in) {
+                            if (lane == 0) base = static_end + atomicAdd(&me->head_trace, chunk);
+                            base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
+                        }
                         if (base >= n_in) {
                             drained = true; chunk_next = chunk_end = 0;
 #if RTX_WAVE_TALLY
-                            clk_drained = clock64();
+                            clk_drained = RTX_TICK();
 #endif
                         }
                         else {
@@ -2097,24 +2140,43 @@ k_trace(const Launch* __restrict__ Lp, GenCtrl* ctrl, const int gen, double* __r
                         chunk_next += take;
                     }
                 }
+#if RTX_WAVE_TALLY
+                const long long l0 = RTX_TICK();
+#endif
                 if (fresh || L.state == LS_JOB_DONE || L.state == LS_NEED_JOB)
                     service_lane<COUNT, FAST, (WIDE == 0 && !COUNT) ? RTX_REPLAY_CAP : 0, NEST>(Lp, oc, gen, accum, aov, L, inst_bits, stk, fresh, tl);
+#if RTX_WAVE_TALLY
+                clk_lane += RTX_TICK() - l0;
+#endif
                 if (drained || __ballot(L.state == LS_EMPTY) == 0ull) break;
             }
             if (COUNT) { tl.clk_serv += (unsigned long long)(clock64() - c0); tl.passes++; }
+#if RTX_WAVE_TALLY
+            clk_service += RTX_TICK() - s0; if (RTX_WAVE_TALLY != 3) n_passes++;
+#endif
             continue;
         }
         if (m_trav == 0ull) break;
         const long long c1 = COUNT ? clock64() : 0;
+#if RTX_WAVE_TALLY
+        const long long t0 = RTX_TICK();
+#endif
         const unsigned long long m_wide = traverse_steps<COUNT, WIDE, NEST>(S, wv, L, stk, inst_bits, service_threshold, !drained, wide_lanes, wide_age, tl, n_records);
 #if RTX_WAVE_TALLY
-        const long long w0 = clock64();
+        const long long w0 = RTX_TICK();
+        clk_steps += w0 - t0;
 #endif
-        if (!COUNT && WIDE != 0 && m_wide != 0ull) wide_jobs(S, wv, L, stk, inst_bits, m_wide);
+        WideOut wide_longest = {};
+        if (!COUNT && WIDE != 0 && m_wide != 0ull) wide_longest = wide_jobs(S, wv, L, stk, inst_bits, m_wide);
+        (void)wide_longest;
 #if RTX_WAVE_TALLY
         if (m_wide != 0ull) {          // what running these jobs side by side instead of one after the other could save at most
             const long long n = __popcll(m_wide);
-            clk_wide_saving += (clock64() - w0) * (n - 1) / n;
+            clk_wide_saving += (RTX_TICK() - w0) * (n - 1) / n;
+            clk_wide += RTX_TICK() - w0; n_wide_jobs += (unsigned)n;
+            if (RTX_WAVE_TALLY == 3 && (unsigned)wide_longest.steps > n_passes) {       // (the longest job's steps instead of the passes)
+                n_passes = (unsigned)wide_longest.steps; wl = wide_longest;
+            }
         }
 #endif
         if (COUNT) tl.clk_trav += (unsigned long long)(clock64() - c1);
@@ -2124,14 +2186,24 @@ k_trace(const Launch* __restrict__ Lp, GenCtrl* ctrl, const int gen, double* __r
 #if RTX_WAVE_TALLY
     // diagnostic builds: lifetimes of this generation's waves (sum, maximum, count) in its control block's padding
     if (lane == 0) {
-        const unsigned long long life = (unsigned long long)(clock64() - clk_begin_all);
+        const unsigned long long life = (unsigned long long)(RTX_TICK() - clk_begin_all);
         atomicAdd((unsigned long long*)&me->tally[8], life);
-        atomicMax((unsigned long long*)&me->tally[10], life);
+        // the longest wave and what it spent its time on: lifetime in units of 64 ticks, then per cent of it
+        // in wave-wide jobs, in traversal steps and in service passes, then its numbers of wave-wide jobs and of service passes
+        atomicMax((unsigned long long*)&me->tally[10], ((life >> 6) << 38) | ((unsigned long long)(clk_wide * 100 / (long long)life) << 31) |
+                  ((unsigned long long)((RTX_WAVE_TALLY == 2 ? clk_lane : clk_steps) * 100 / (long long)life) << 24) | ((unsigned long long)(clk_service * 100 / (long long)life) << 17) |
+                  ((unsigned long long)(n_wide_jobs > 255u ? 255u : n_wide_jobs) << 9) | (n_passes > 511u ? 511u : n_passes));
         atomicAdd(&me->tally[12], 1u);
         const unsigned bin = (unsigned)(life / (150ull * 2400ull));          // 150 us bins at 2.4 GHz
-        atomicAdd(&me->tally[bin < 6u ? bin : 6u], 1u);
+        if (RTX_WAVE_TALLY != 3) atomicAdd(&me->tally[bin < 6u ? bin : 6u], 1u);
+        else {      // instead of the bins: where the longest wave's longest wave-wide job spent its ticks (keyed by the lifetime)
+            atomicMax((unsigned long long*)&me->tally[0], ((life >> 6) << 38) | wl.t_seed);
+            atomicMax((unsigned long long*)&me->tally[2], ((life >> 6) << 38) | wl.t_pop);
+            atomicMax((unsigned long long*)&me->tally[4], ((life >> 6) << 38) | wl.t_load);
+            if (wl.t_rest) atomicMax(&me->tally[6], wl.t_rest);         // (not keyed: the longest anywhere)
+        }
         // ... and how long the wave went on after it found the queue dry (sum and maximum)
-        const unsigned long long after = (unsigned long long)(clock64() - clk_drained);
+        const unsigned long long after = (unsigned long long)(RTX_TICK() - clk_drained);
         atomicAdd((unsigned long long*)&me->tally[14], after);
         atomicMax(&me->tally[13], (unsigned)(after >> 8));
         // the longest lifetime if wave-wide jobs of one wave ran side by side (tally[7], units of 256 ticks, replaces the last bin)
