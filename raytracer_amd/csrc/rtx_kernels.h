@@ -1434,10 +1434,10 @@ RTX_DEV void cand_swap(Cand& a, Cand& b, bool doit) {
 #define RTX_WIDE_LANES_THIN 6        // the two thresholds in generations below RTX_SCATTER_THIN_RAYS rays
 #endif
 #ifndef RTX_WIDE_AGE_THIN
-#define RTX_WIDE_AGE_THIN 32
+#define RTX_WIDE_AGE_THIN 8
 #endif
 #ifndef RTX_WIDE_AGE
-#define RTX_WIDE_AGE 32              // in a generation of size: only jobs that have taken this many steps already
+#define RTX_WIDE_AGE 8               // in a generation of size: only jobs that have taken this many steps already
 #endif
 #define RTX_WIDE_CAP 480             // frontier entries (32 bytes) in the wave's LDS rows
 #define RTX_WIDE_KEY_SHIFT 52        // first record level's two key bits; ten bits above them for the starting rank
