@@ -1425,13 +1425,13 @@ RTX_DEV void cand_swap(Cand& a, Cand& b, bool doit) {
 // order; within a leaf the triangle's position.  Every triangle is tested against the incoming
 // bound and the minimum of (t, key, triangle) is taken at the end.
 #ifndef RTX_WIDE_LANES
-#define RTX_WIDE_LANES 10            // at most this many unfinished jobs in a drained wave: run them wave-wide
+#define RTX_WIDE_LANES 24            // at most this many unfinished jobs in a drained wave: run them wave-wide
 #endif
 #ifndef RTX_WIDE_MAX_RAYS
 #define RTX_WIDE_MAX_RAYS 512        // generations with at most this many rays use it
 #endif
 #ifndef RTX_WIDE_LANES_THIN
-#define RTX_WIDE_LANES_THIN 6        // the two thresholds in generations below RTX_SCATTER_THIN_RAYS rays
+#define RTX_WIDE_LANES_THIN 16       // the two thresholds in generations below RTX_SCATTER_THIN_RAYS rays
 #endif
 #ifndef RTX_WIDE_AGE_THIN
 #define RTX_WIDE_AGE_THIN 8
@@ -1439,7 +1439,8 @@ RTX_DEV void cand_swap(Cand& a, Cand& b, bool doit) {
 #ifndef RTX_WIDE_AGE
 #define RTX_WIDE_AGE 8               // in a generation of size: only jobs that have taken this many steps already
 #endif
-#define RTX_WIDE_CAP 480             // frontier entries (32 bytes) in the wave's LDS rows
+#define RTX_WIDE_CAP 432             // frontier entries (32 bytes) in the wave's LDS rows, the jobs' slots behind them
+#define RTX_WIDE_JOBS 16             // jobs traversed side by side (128-byte slots)
 #define RTX_WIDE_KEY_SHIFT 52        // first record level's two key bits; ten bits above them for the starting rank
 
 RTX_DEV double bcast_d(double v, int src) {
@@ -1474,49 +1475,68 @@ RTX_DEV int wave_max_i(int v) {
 // What the wave needs of the owner's lane, and what it hands back.  Passed by value: the function is
 // not inlined (inlined, its registers spoil the allocation of the traversal loop around the call).
 struct WideIn { double rox, roy, roz, rdx, rdy, rdz, ix, iy, iz, t_min, stop; int par, shadow, sp, cur_ref, cur_cnt; v4i top; };
-struct WideOut { double t_min; int btri, wmin, wmax, steps; unsigned t_seed, t_pop, t_load, t_rest; };
+struct WideOut { double t_min; int btri, wmin, wmax, steps; unsigned t_seed, t_pop, t_load, t_rest; unsigned long long sel; };
 
-__device__ __attribute__((noinline)) WideOut wide_job(const Scene& S, const Wave wv, const WideIn L, glob_v4i* stk, unsigned* inst_bits,
-                                                      const int src) {
+// The jobs of the lanes in `m` (at most RTX_WIDE_JOBS, their stacks together within the frontier's
+// room: the caller sees to both), traversed by the whole wave *side by side*: one frontier holds the
+// open nodes of all of them, an entry names its job, and a lane takes whatever entry is its turn.  What
+// a job needs lies in a 128-byte slot behind the frontier: the ray, the incoming bound, and the best hit
+// so far, whose distance is the job's current bound.  Hits that improve a slot are rare and are written
+// one lane after the other.  Each owner lane gets its own job's result.
+__device__ __attribute__((noinline)) WideOut wide_multi(const Scene& S, const Wave wv, const WideIn L, glob_v4i* stk, unsigned* inst_bits,
+                                                        const unsigned long long m_all) {
     const unsigned lane = wv.lane;
-    const char* const blas = S.blas;
-    const unsigned n_summary = rtx_summary_words(S.n_insts);
-    // the owner's job, wave-uniform
-    Slab sl;
-    sl.ox = bcast_d(L.rox, src); sl.oy = bcast_d(L.roy, src); sl.oz = bcast_d(L.roz, src);
-    sl.ix = bcast_d(L.ix, src); sl.iy = bcast_d(L.iy, src); sl.iz = bcast_d(L.iz, src);
-    sl.par = __builtin_amdgcn_readlane(L.par, src);
-    const V3 ro = mk(sl.ox, sl.oy, sl.oz);
-    const V3 rd = mk(bcast_d(L.rdx, src), bcast_d(L.rdy, src), bcast_d(L.rdz, src));
-    const double b_init = bcast_d(L.t_min, src);
-    const double stop = bcast_d(L.stop, src);
-    const bool any_hit = (__builtin_amdgcn_readlane(L.shadow, src) & 2) != 0;
-    const int o_sp = __builtin_amdgcn_readlane(L.sp, src);
-    const unsigned long long stk_a = (unsigned long long)(size_t)stk, bits_a = (unsigned long long)(size_t)inst_bits;
-    const glob_v4i* o_stk = (const glob_v4i*)(size_t)(((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(stk_a >> 32), src) << 32) |
-                                                       (unsigned)__builtin_amdgcn_readlane((int)stk_a, src));
-    unsigned* o_bits = (unsigned*)(size_t)(((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(bits_a >> 32), src) << 32) |
-                                           (unsigned)__builtin_amdgcn_readlane((int)bits_a, src));
-    const bool cull = S.cull != 0;
-    const double isect_eps = S.isect_eps;
-
-#if RTX_WAVE_TALLY == 3
-    long long k0 = RTX_TICK(), k_seed = 0, k_pop = 0, k_load = 0, k_rest = 0;
-#endif
-    // frontier: entry i = two 16-byte halves {enter, ref, cnt} {key, shift, -}; the owner's stack from
-    // the bottom, its register-held top, and on top of everything the node it is at
-    lds_v4i* F = (lds_v4i*)wv.rows;
-    __builtin_amdgcn_wave_barrier();
-    for (int base = 0; base < o_sp - 1; base += 64) {
-        const int i = base + (int)lane;
-        if (i < o_sp - 1) {
-            const v4i e = o_stk[i];
-            const unsigned long long key = (unsigned long long)(unsigned)(o_sp - i) << (RTX_WIDE_KEY_SHIFT + 2);
-            v4i k; k.x = (int)(unsigned)key; k.y = (int)(unsigned)(key >> 32); k.z = RTX_WIDE_KEY_SHIFT; k.w = 0;
-            F[2 * i] = e; F[2 * i + 1] = k;
+    // this call's jobs: as many of m_all as there are slots and as their stacks leave the frontier room
+    unsigned long long m = 0ull;
+    {
+        int seeds = 0, n = 0;
+        for (unsigned long long mm = m_all; mm != 0ull && n < RTX_WIDE_JOBS; mm &= mm - 1ull, n++) {
+            const int src = __ffsll((long long)mm) - 1;
+            const int need = __builtin_amdgcn_readlane(L.sp, src) + 1;
+            if (n > 0 && seeds + need > RTX_WIDE_CAP - 104 - 3) break;
+            m |= 1ull << src; seeds += need;
         }
     }
-    {
+    const char* const blas = S.blas;
+    const unsigned n_summary = rtx_summary_words(S.n_insts);
+    const bool cull = S.cull != 0;
+    const double isect_eps = S.isect_eps;
+    const unsigned long long stk_a = (unsigned long long)(size_t)stk, bits_a = (unsigned long long)(size_t)inst_bits;
+
+    // frontier: entry i = two 16-byte halves {enter, ref, cnt} {key, shift, job}
+    lds_v4i* F = (lds_v4i*)wv.rows;
+    // slot of a job, 16 doubles: slab origin and inverse direction (0-5), direction (6-8), incoming bound (9),
+    // any-hit threshold (10), best t = current bound (11), best key (12), address of the owner's instance
+    // bitmap (13), {flags, best triangle} (14), {lowest, highest bitmap word marked} (15)
+    lds_double* T = wv.rows + RTX_WIDE_CAP * 4;
+    const bool mine = ((m >> lane) & 1ull) != 0ull;
+    const int my_slot = __popcll(m & ((1ull << lane) - 1ull));
+    __builtin_amdgcn_wave_barrier();
+    if (mine) {
+        lds_double* t = T + 16 * my_slot;
+        t[0] = L.rox; t[1] = L.roy; t[2] = L.roz; t[3] = L.ix; t[4] = L.iy; t[5] = L.iz;
+        t[6] = L.rdx; t[7] = L.rdy; t[8] = L.rdz; t[9] = L.t_min; t[10] = L.stop; t[11] = L.t_min;
+        t[12] = __hiloint2double(-1, -1);
+        t[13] = __hiloint2double((int)(bits_a >> 32), (int)bits_a);
+        t[14] = __hiloint2double(INT_MAX, L.par | ((L.shadow & 2) ? 256 : 0));
+        t[15] = __hiloint2double(-1, INT_MAX);
+    }
+    // every job's stack from the bottom, its register-held top, and on top of those the node it is at
+    int count = 0, n_slots = 0;
+    for (unsigned long long mm = m; mm != 0ull; mm &= mm - 1ull, n_slots++) {
+        const int src = __ffsll((long long)mm) - 1;
+        const int o_sp = __builtin_amdgcn_readlane(L.sp, src);
+        const glob_v4i* o_stk = (const glob_v4i*)(size_t)(((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(stk_a >> 32), src) << 32) |
+                                                           (unsigned)__builtin_amdgcn_readlane((int)stk_a, src));
+        for (int base = 0; base < o_sp - 1; base += 64) {
+            const int i = base + (int)lane;
+            if (i < o_sp - 1) {
+                const v4i e = o_stk[i];
+                const unsigned long long key = (unsigned long long)(unsigned)(o_sp - i) << (RTX_WIDE_KEY_SHIFT + 2);
+                v4i k; k.x = (int)(unsigned)key; k.y = (int)(unsigned)(key >> 32); k.z = RTX_WIDE_KEY_SHIFT; k.w = n_slots;
+                F[2 * (count + i)] = e; F[2 * (count + i) + 1] = k;
+            }
+        }
         v4i t;
         t.x = __builtin_amdgcn_readlane(L.top.x, src); t.y = __builtin_amdgcn_readlane(L.top.y, src);
         t.z = __builtin_amdgcn_readlane(L.top.z, src); t.w = __builtin_amdgcn_readlane(L.top.w, src);
@@ -1524,79 +1544,84 @@ __device__ __attribute__((noinline)) WideOut wide_job(const Scene& S, const Wave
         c.x = __double2loint(-DBL_MAX); c.y = __double2hiint(-DBL_MAX);
         c.z = __builtin_amdgcn_readlane(L.cur_ref, src); c.w = __builtin_amdgcn_readlane(L.cur_cnt, src);
         if (lane == 0) {
-            v4i k; k.z = RTX_WIDE_KEY_SHIFT; k.w = 0;
+            v4i k; k.z = RTX_WIDE_KEY_SHIFT; k.w = n_slots;
             if (o_sp > 0) {
                 const unsigned long long key = 1ull << (RTX_WIDE_KEY_SHIFT + 2);
                 k.x = (int)(unsigned)key; k.y = (int)(unsigned)(key >> 32);
-                F[2 * (o_sp - 1)] = t; F[2 * (o_sp - 1) + 1] = k;
+                F[2 * (count + o_sp - 1)] = t; F[2 * (count + o_sp - 1) + 1] = k;
             }
             k.x = 0; k.y = 0;
-            F[2 * o_sp] = c; F[2 * o_sp + 1] = k;
+            F[2 * (count + o_sp)] = c; F[2 * (count + o_sp) + 1] = k;
         }
+        count += o_sp + 1;
     }
-    int count = o_sp + 1;
     __builtin_amdgcn_s_waitcnt(0xC07F);
     __builtin_amdgcn_wave_barrier();
 
-    double B = b_init;                                   // current bound, identical in all lanes
-    double best_t = INFINITY;
-    unsigned long long best_key = ~0ull;
-    int best_tri = INT_MAX;
-    int wmin = INT_MAX, wmax = -1;
-    int n_steps = 0;
-#if RTX_WAVE_TALLY == 3
-    { const long long k1 = RTX_TICK(); k_seed = k1 - k0; k0 = k1; }
+#if RTX_WIDE_TALLY
+    unsigned w_steps = 0, w_active = 0, w_go = 0, w_seeds = (unsigned)count;
 #endif
     while (count > 0) {
-        n_steps++;
-        int W = (RTX_WIDE_CAP - 104 - count) / 4;        // room for four pushes per lane, and for a depth-first descent when it is tight
-        W = W > 64 ? 64 : (W < 1 ? 1 : W);
+        // The top 64 entries, one per lane, as long as the frontier stays below its limit (see the append);
+        // above it the wave descends depth-first from the top entry.
+        int W = count <= RTX_WIDE_CAP - 104 - 3 ? 64 : 1;
         W = W > count ? count : W;
         const bool active = (int)lane < W;
         const int idx = count - 1 - (int)lane;
         count -= W;
         v4i ea = (v4i)(0), eb = (v4i)(0);
         if (active) { ea = F[2 * idx]; eb = F[2 * idx + 1]; }
+        lds_double* const t = T + 16 * eb.w;
+        const lds_v2d* const t2 = (const lds_v2d*)t;
+        const v2d stop_b = t2[5];                         // {any-hit threshold, current bound}
+        const int flags = __double2loint(t[14]);
         __builtin_amdgcn_s_waitcnt(0xC07F);
         __builtin_amdgcn_wave_barrier();
-        const bool go = active && B >= __hiloint2double(ea.y, ea.x);
+        const double B = stop_b.y;
+        const bool go = active && B >= __hiloint2double(ea.y, ea.x) && !((flags & 256) && B < stop_b.x);
+#if RTX_WIDE_TALLY
+        w_steps++; w_active += (unsigned)W; w_go += (unsigned)__popcll(__ballot(go));
+#endif
         const int ref = ea.z, cnt = ea.w;
         const unsigned long long key = ((unsigned long long)(unsigned)eb.y << 32) | (unsigned)eb.x;
         const int shift = eb.z;
         double rec[32];
-#if RTX_WAVE_TALLY == 3
-        { const long long k1 = RTX_TICK(); k_pop += k1 - k0; k0 = k1; }
-#endif
+        Slab sl; V3 rd = mk(0, 0, 1);
+        sl.ox = sl.oy = sl.oz = sl.ix = sl.iy = sl.iz = 0.0; sl.par = flags & 255;
         if (go) {
             const RTX_GLOBAL v2d* gp = (const RTX_GLOBAL v2d*)(blas + ((size_t)(unsigned)ref << 7));
 #pragma unroll
             for (int p = 0; p < 16; p++) { const v2d v = gp[p]; rec[2 * p] = v.x; rec[2 * p + 1] = v.y; }
+            const v2d a = t2[0], b = t2[1], c = t2[2], d = t2[3];
+            sl.ox = a.x; sl.oy = a.y; sl.oz = b.x; sl.ix = b.y; sl.iy = c.x; sl.iz = c.y;
+            rd = mk(d.x, d.y, t[8]);
         }
-#if RTX_WAVE_TALLY == 3
-        { const long long k1 = RTX_TICK(); k_load += k1 - k0; k0 = k1; }
-#endif
         // What this lane puts back: up to four entries, farthest first.  (Slot k of c[] goes back if
         // c[k].ok, behind the slots above it: fixed places, no list built at run time, which would
-        // live in memory instead of registers.)  rank_of < 0: the rest of a leaf, the key stays.
+        // live in memory instead of registers.)  leaf_rest: the rest of a leaf, the key stays.
         Cand c[4];
         c[0].ok = c[1].ok = c[2].ok = c[3].ok = false;
         c[0].e = c[1].e = c[2].e = c[3].e = 0.0; c[0].ref = c[1].ref = c[2].ref = c[3].ref = 0; c[0].cnt = c[1].cnt = c[2].cnt = c[3].cnt = 0;
         bool leaf_rest = false;
+        bool hit = false; double ht = 0.0; int htri = 0;
+        int wlo = INT_MAX, whi = -1;
         if (go && cnt == 0) {
 #pragma unroll
             for (int k = 0; k < 4; k++) {
                 c[k].ref = k & 1 ? __double2hiint(rec[24 + (k >> 1)]) : __double2loint(rec[24 + (k >> 1)]);
                 c[k].cnt = k & 1 ? __double2hiint(rec[26 + (k >> 1)]) : __double2loint(rec[26 + (k >> 1)]);
                 double e;
-                const bool hit = box_enter(rec + 6 * k, rec + 6 * k + 3, sl, e);
+                const bool hitb = box_enter(rec + 6 * k, rec + 6 * k + 3, sl, e);
                 c[k].e = e;
-                const bool pass = hit & (B >= e);
+                const bool pass = hitb & (B >= e);
                 c[k].ok = pass & (c[k].cnt >= 0);
                 if (pass && c[k].cnt == -2) {            // TLAS walk: candidate instance
+                    const double ba = t[13];
+                    unsigned* o_bits = (unsigned*)(size_t)(((unsigned long long)(unsigned)__double2hiint(ba) << 32) | (unsigned)__double2loint(ba));
                     const int w = c[k].ref >> 5;
                     atomicOr(o_bits + n_summary + w, 1u << (c[k].ref & 31));
                     atomicOr(o_bits + (w >> 5), 1u << (w & 31));
-                    wmin = min(wmin, w); wmax = max(wmax, w);
+                    wlo = min(wlo, w); whi = max(whi, w);
                 }
             }
             const int axis0 = __double2loint(rec[28]), axisL = __double2hiint(rec[28]), axisR = __double2loint(rec[29]);
@@ -1611,19 +1636,22 @@ __device__ __attribute__((noinline)) WideOut wide_job(const Scene& S, const Wave
         } else if (go && cnt > 0) {
             const double* td = rec;
             const double* tq = rec + 16;
+            const V3 ro = mk(sl.ox, sl.oy, sl.oz);
+            const double b_init = t[9];
             const bool two = cnt >= 2;
             bool culled0 = false, culled1 = false;
             if (cull) {
                 culled0 = rd.x * td[10] + rd.y * td[11] + rd.z * td[12] > 0.0;
                 culled1 = rd.x * tq[10] + rd.y * tq[11] + rd.z * tq[12] > 0.0;
             }
-            double t, b, g2;
-            if (!culled0 && tri_test(td, ro, rd, b_init, isect_eps, t, b, g2)) {
-                if (t < best_t || (t == best_t && (key < best_key || (key == best_key && ref < best_tri)))) { best_t = t; best_key = key; best_tri = ref; }
+            // every triangle is tested against the incoming bound, so that a tie with the best so far is seen
+            double tt, b, g2;
+            if (!culled0 && tri_test(td, ro, rd, b_init, isect_eps, tt, b, g2)) { hit = true; ht = tt; htri = ref; }
+            if (two && !culled1 && tri_test(tq, ro, rd, b_init, isect_eps, tt, b, g2)) {
+                if (!hit || tt < ht) { ht = tt; htri = ref + 1; }
+                hit = true;
             }
-            if (two && !culled1 && tri_test(tq, ro, rd, b_init, isect_eps, t, b, g2)) {
-                if (t < best_t || (t == best_t && (key < best_key || (key == best_key && ref + 1 < best_tri)))) { best_t = t; best_key = key; best_tri = ref + 1; }
-            }
+            hit = hit && ht <= B;
             if (cnt > 2) {
                 // the rest of a long leaf (a mesh without a BVH is one leaf): in two halves, so that
                 // the lanes working on it double with every round
@@ -1635,11 +1663,47 @@ __device__ __attribute__((noinline)) WideOut wide_job(const Scene& S, const Wave
                 if (rest > h) { c[2].ref = ref + 2 + h; c[2].cnt = rest - h; c[2].ok = true; }
             }
         }
+        // the slots' best hits and marked ranges: one lane after the other
+        for (unsigned long long mc = __ballot(hit || whi >= 0); mc != 0ull; mc &= mc - 1ull) {
+            if ((int)lane == __ffsll((long long)mc) - 1) {
+                if (hit) {
+                    const double bt = t[11], bk_d = t[12];
+                    const unsigned long long bk = ((unsigned long long)(unsigned)__double2hiint(bk_d) << 32) | (unsigned)__double2loint(bk_d);
+                    const int btri = __double2hiint(t[14]);
+                    if (ht < bt || (ht == bt && (key < bk || (key == bk && htri < btri)))) {
+                        t[11] = ht; t[12] = __hiloint2double((int)(unsigned)(key >> 32), (int)(unsigned)key);
+                        t[14] = __hiloint2double(htri, flags);
+                    }
+                }
+                if (whi >= 0) {
+                    const double r = t[15];
+                    t[15] = __hiloint2double(max(__double2hiint(r), whi), min(__double2loint(r), wlo));
+                }
+            }
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+            __builtin_amdgcn_wave_barrier();
+        }
         // append: exclusive prefix of the push counts over the lanes
-        const int npush = (int)c[0].ok + (int)c[1].ok + (int)c[2].ok + (int)c[3].ok;
+        int npush = (int)c[0].ok + (int)c[1].ok + (int)c[2].ok + (int)c[3].ok;
         int incl = npush;
         for (int off = 1; off < 64; off <<= 1) { const int o = __shfl_up(incl, off); if ((int)lane >= off) incl += o; }
-        const int total = __shfl(incl, 63);
+        int total = __shfl(incl, 63);
+        if (W > 1 && count + total > RTX_WIDE_CAP - 104) {
+            // More children than the frontier may hold: the leading lanes whose children fit put them
+            // back, the others their own entry, to be taken again (what they found meanwhile stands: a
+            // best hit and a mark are the same the second time).  Lane 0 always fits, by the choice of W.
+            const int room = RTX_WIDE_CAP - 104 - count;
+            const unsigned long long fm = __ballot(active && incl + (W - 1 - (int)lane) <= room);
+            const int p = __ffsll((long long)~fm) - 1;
+            if ((int)lane >= p) {
+                c[0].ok = c[1].ok = c[2].ok = false;
+                c[3].ok = go; c[3].e = __hiloint2double(ea.y, ea.x); c[3].ref = ref; c[3].cnt = cnt; leaf_rest = true;
+                npush = go ? 1 : 0;
+            }
+            incl = npush;
+            for (int off = 1; off < 64; off <<= 1) { const int o = __shfl_up(incl, off); if ((int)lane >= off) incl += o; }
+            total = __shfl(incl, 63);
+        }
         int at = count + incl - npush;
 #pragma unroll
         for (int k = 3; k >= 0; k--) {
@@ -1647,62 +1711,62 @@ __device__ __attribute__((noinline)) WideOut wide_job(const Scene& S, const Wave
                 v4i a; a.x = __double2loint(c[k].e); a.y = __double2hiint(c[k].e); a.z = c[k].ref; a.w = c[k].cnt;
                 unsigned long long k2 = key; int sh = shift;
                 if (!leaf_rest) { k2 = key | ((unsigned long long)(unsigned)k << (shift > 0 ? shift : 0)); sh = shift - 2; }
-                v4i bb; bb.x = (int)(unsigned)k2; bb.y = (int)(unsigned)(k2 >> 32); bb.z = sh; bb.w = 0;
+                v4i bb; bb.x = (int)(unsigned)k2; bb.y = (int)(unsigned)(k2 >> 32); bb.z = sh; bb.w = eb.w;
                 F[2 * at] = a; F[2 * at + 1] = bb;
                 at++;
             }
         }
         count += total;
-        // Cannot happen, so there is nothing to report: while W is computed, count + 3 W stays below
-        // RTX_WIDE_CAP - 104; once W is forced to 1 the wave descends depth-first from the top entry,
-        // which adds at most three entries per record level (at most 26 levels, Launch::wide_ok) plus
-        // one per halving of a long leaf (< 26): fewer than the 104 entries held back.
+        // Cannot happen, so there is nothing to report: with all lanes at work the frontier ends a step
+        // at RTX_WIDE_CAP - 104 entries or below; once W is 1 the wave descends depth-first from the top
+        // entry, which adds at most three entries per record level (at most 26 levels, Launch::wide_ok)
+        // plus one per halving of a long leaf (< 26): fewer than the 104 entries held back.
         if (count > RTX_WIDE_CAP) count = RTX_WIDE_CAP;
         __builtin_amdgcn_s_waitcnt(0xC07F);
         __builtin_amdgcn_wave_barrier();
-        const double m = wave_min_d(best_t);
-        B = m < B ? m : B;
-#if RTX_WAVE_TALLY == 3
-        { const long long k1 = RTX_TICK(); k_rest += k1 - k0; k0 = k1; }
-#endif
-        if (any_hit && B < stop) break;
     }
-    // the winner: smallest t, then first in the reference's visiting order
-    const double tmin = wave_min_d(best_t);
-    const unsigned long long kmin = wave_min_u64(best_t == tmin ? best_key : ~0ull);
-    const int trmin = wave_min_i((best_t == tmin && best_key == kmin) ? best_tri : INT_MAX);
-    const int all_wmin = wave_min_i(wmin), all_wmax = wave_max_i(wmax);
-    WideOut out;
-    out.t_min = tmin; out.btri = trmin; out.wmin = all_wmin; out.wmax = all_wmax; out.steps = n_steps;
-    out.t_seed = out.t_pop = out.t_load = out.t_rest = 0;
-#if RTX_WAVE_TALLY == 3
-    out.t_seed = (unsigned)k_seed; out.t_pop = (unsigned)k_pop; out.t_load = (unsigned)k_load; out.t_rest = (unsigned)k_rest;
+#if RTX_WIDE_TALLY
+    if (lane == 0) {      // diagnostic builds: calls, jobs, steps, lanes with an entry, lanes that fetched, entries at the start
+        unsigned* tw = S.limit_flag + (offsetof(GenCtrl, search_back) - offsetof(GenCtrl, limit)) / 4;
+        atomicAdd(tw, 1u); atomicAdd(tw + 1, (unsigned)n_slots); atomicAdd(tw + 2, w_steps); atomicAdd(tw + 3, w_active);
+        atomicAdd(tw + 4, w_go); atomicAdd(tw + 5, w_seeds);
+    }
 #endif
+    // every owner's result: smallest t, then first in the reference's visiting order
+    WideOut out;
+    out.t_min = INFINITY; out.btri = -1; out.wmin = INT_MAX; out.wmax = -1; out.steps = 0;
+    out.t_seed = out.t_pop = out.t_load = out.t_rest = 0; out.sel = m;
+    if (mine) {
+        const lds_double* t = T + 16 * my_slot;
+        const double bk_d = t[12], tr = t[14], r = t[15];
+        if ((__double2hiint(bk_d) & __double2loint(bk_d)) != -1) { out.t_min = t[11]; out.btri = __double2hiint(tr); }
+        out.wmin = __double2loint(r); out.wmax = __double2hiint(r);
+    }
     __builtin_amdgcn_wave_barrier();
     return out;
 }
 
-// Run the jobs of the lanes in `m` wave-wide, one after the other.
+// Run the jobs of the lanes in `m` wave-wide, as many at a time as wide_multi takes.
 RTX_DEV WideOut wide_jobs(const Scene& S, const Wave& wv, Lane& L, glob_v4i* stk, unsigned* inst_bits,
                           unsigned long long m) {
-    WideOut longest = {};       // (the job of most steps: diagnostic builds report it)
     WideIn in;
     in.rox = L.ro.x; in.roy = L.ro.y; in.roz = L.ro.z; in.rdx = L.rd.x; in.rdy = L.rd.y; in.rdz = L.rd.z;
     in.ix = L.ix; in.iy = L.iy; in.iz = L.iz; in.t_min = L.t_min; in.stop = L.orig_t_min;
     in.par = L.par; in.shadow = L.is_shadow; in.sp = L.sp; in.cur_ref = L.cur_ref; in.cur_cnt = L.cur_cnt; in.top = L.top;
+    WideOut out = {};
     while (m != 0ull) {
-        const int src = __ffsll((long long)m) - 1;
-        m &= m - 1ull;
-        const WideOut out = wide_job(S, wv, in, stk, inst_bits, src);
-        if (out.steps > longest.steps) longest = out;
-        if ((int)wv.lane == src) {
+        out = wide_multi(S, wv, in, stk, inst_bits, m);
+        const unsigned long long sel = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(out.sel >> 32)) << 32) |
+                                       (unsigned)__builtin_amdgcn_readfirstlane((int)out.sel);
+        m &= ~sel;
+        if ((sel >> wv.lane) & 1ull) {
             if (out.t_min < INFINITY) { L.t_min = out.t_min; L.btri = out.btri; }
             L.word = min(L.word, out.wmin); L.whi = max(L.whi, out.wmax);
             L.sp = 0;
             L.state = LS_JOB_DONE;
         }
     }
-    return longest;
+    return out;
 }
 
 // NEST (1: consistent mode, 2: exact mode's search): instances are not collected for a replay in
