@@ -1439,8 +1439,11 @@ RTX_DEV void cand_swap(Cand& a, Cand& b, bool doit) {
 #ifndef RTX_WIDE_AGE
 #define RTX_WIDE_AGE 8               // in a generation of size: only jobs that have taken this many steps already
 #endif
+#ifndef RTX_WIDE_CAP
 #define RTX_WIDE_CAP 432             // frontier entries (32 bytes) in the wave's LDS rows, the jobs' slots behind them
+#endif
 #define RTX_WIDE_JOBS 16             // jobs traversed side by side (128-byte slots)
+static_assert(RTX_WIDE_CAP * 32 + RTX_WIDE_JOBS * 128 <= 64 * RTX_ROW_DOUBLES * 8, "frontier and job slots share the wave's LDS rows");
 #define RTX_WIDE_KEY_SHIFT 52        // first record level's two key bits; ten bits above them for the starting rank
 
 RTX_DEV double bcast_d(double v, int src) {
@@ -1472,6 +1475,17 @@ RTX_DEV int wave_max_i(int v) {
                          const long long t_ = (long long)__builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
                          __builtin_amdgcn_sched_barrier(0); return t_; }())
 #endif
+// Exclusive prefix sum and total over the wave of a number between 0 and 7 per lane: three ballots
+// and their bit counts below the lane, instead of six rounds through the cross-lane network.
+RTX_DEV void small_prefix(const int v, int& excl, int& total) {
+    const unsigned long long b0 = __ballot((v & 1) != 0), b1 = __ballot((v & 2) != 0), b2 = __ballot((v & 4) != 0);
+    const unsigned c0 = __builtin_amdgcn_mbcnt_hi((unsigned)(b0 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b0, 0u));
+    const unsigned c1 = __builtin_amdgcn_mbcnt_hi((unsigned)(b1 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b1, 0u));
+    const unsigned c2 = __builtin_amdgcn_mbcnt_hi((unsigned)(b2 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b2, 0u));
+    excl = (int)(c0 + 2u * c1 + 4u * c2);
+    total = __popcll(b0) + 2 * __popcll(b1) + 4 * __popcll(b2);
+}
+
 // What the wave needs of the owner's lane, and what it hands back.  Passed by value: the function is
 // not inlined (inlined, its registers spoil the allocation of the traversal loop around the call).
 struct WideIn { double rox, roy, roz, rdx, rdy, rdz, ix, iy, iz, t_min, stop; int par, shadow, sp, cur_ref, cur_cnt; v4i top; };
@@ -1685,26 +1699,23 @@ __device__ __attribute__((noinline)) WideOut wide_multi(const Scene& S, const Wa
         }
         // append: exclusive prefix of the push counts over the lanes
         int npush = (int)c[0].ok + (int)c[1].ok + (int)c[2].ok + (int)c[3].ok;
-        int incl = npush;
-        for (int off = 1; off < 64; off <<= 1) { const int o = __shfl_up(incl, off); if ((int)lane >= off) incl += o; }
-        int total = __shfl(incl, 63);
+        int excl, total;
+        small_prefix(npush, excl, total);
         if (W > 1 && count + total > RTX_WIDE_CAP - 104) {
             // More children than the frontier may hold: the leading lanes whose children fit put them
             // back, the others their own entry, to be taken again (what they found meanwhile stands: a
             // best hit and a mark are the same the second time).  Lane 0 always fits, by the choice of W.
             const int room = RTX_WIDE_CAP - 104 - count;
-            const unsigned long long fm = __ballot(active && incl + (W - 1 - (int)lane) <= room);
+            const unsigned long long fm = __ballot(active && excl + npush + (W - 1 - (int)lane) <= room);
             const int p = __ffsll((long long)~fm) - 1;
             if ((int)lane >= p) {
                 c[0].ok = c[1].ok = c[2].ok = false;
                 c[3].ok = go; c[3].e = __hiloint2double(ea.y, ea.x); c[3].ref = ref; c[3].cnt = cnt; leaf_rest = true;
                 npush = go ? 1 : 0;
             }
-            incl = npush;
-            for (int off = 1; off < 64; off <<= 1) { const int o = __shfl_up(incl, off); if ((int)lane >= off) incl += o; }
-            total = __shfl(incl, 63);
+            small_prefix(npush, excl, total);
         }
-        int at = count + incl - npush;
+        int at = count + excl;
 #pragma unroll
         for (int k = 3; k >= 0; k--) {
             if (c[k].ok && at < RTX_WIDE_CAP) {
@@ -1717,11 +1728,12 @@ __device__ __attribute__((noinline)) WideOut wide_multi(const Scene& S, const Wa
             }
         }
         count += total;
-        // Cannot happen, so there is nothing to report: with all lanes at work the frontier ends a step
+        // Cannot happen (should it ever, the frame fails rather than show a picture with something
+        // missing): with all lanes at work the frontier ends a step
         // at RTX_WIDE_CAP - 104 entries or below; once W is 1 the wave descends depth-first from the top
         // entry, which adds at most three entries per record level (at most 26 levels, Launch::wide_ok)
         // plus one per halving of a long leaf (< 26): fewer than the 104 entries held back.
-        if (count > RTX_WIDE_CAP) count = RTX_WIDE_CAP;
+        if (count > RTX_WIDE_CAP) { if (lane == 0) *S.limit_flag = 1u; count = RTX_WIDE_CAP; }
         __builtin_amdgcn_s_waitcnt(0xC07F);
         __builtin_amdgcn_wave_barrier();
     }
