@@ -1109,29 +1109,38 @@ RTX_DEV double fresnel_dielectric(double cosTheta, double n1, double n2) {
 
 #define RTX_META(depth, beer) ((unsigned)(depth) | ((unsigned)((beer) + 1) << 8))
 
-// Append one ray per requesting lane: ballot, one reservation per wave, dense stores.
-// `sub` = the wave's sub-queue.  Radiance rays go to slot k of the sub-queue, shadow rays to
-// slot sub_capacity-1-k.  Must be reached by every lane of the wave.
-RTX_DEV void emit(const Queue& q, GenCtrl* next, unsigned sub, bool shadow, bool want, V3 o, V3 d, V3 w, double aux,
-                  unsigned pixel, unsigned meta) {
-    const unsigned long long mask = __ballot(want);
-    if (mask == 0ull) return;
-    const unsigned lane = lane_id();
-    const int leader = __ffsll((long long)mask) - 1;
-    const unsigned n = (unsigned)__popcll(mask);
+// Rays are appended to the wave's sub-queue: radiance rays from slot 0 upwards, shadow rays from
+// slot sub_capacity-1 downwards, both counts in one 64-bit word.  A batch of hits makes ONE
+// reservation for everything it emits (the counts are known before the rays are: a lane emits a
+// shadow ray per light or none) -- the counter of a sub-queue is one address, and atomics on one
+// address are served one after the other, a few tens of nanoseconds each, whoever asks.
+struct Emit {
+    unsigned rad, sh;       // first free slot of this batch's radiance / shadow rays (wave-uniform)
+    bool ok;
+};
+// Must be reached by every lane of the wave.
+RTX_DEV Emit emit_reserve(const Queue& q, GenCtrl* next, unsigned sub, unsigned n_rad, unsigned n_sh) {
+    Emit e; e.rad = 0; e.sh = 0; e.ok = false;
+    if (n_rad + n_sh == 0u) return e;
     unsigned long long old = 0;
-    if ((int)lane == leader)
-        old = atomicAdd(&next->sub[sub].counts, shadow ? ((unsigned long long)n << 32) : (unsigned long long)n);
-    old = __shfl(old, leader);
-    const unsigned base = shadow ? (unsigned)(old >> 32) : (unsigned)old;
-    const unsigned other = shadow ? (unsigned)old : (unsigned)(old >> 32);
+    if (lane_id() == 0u) old = atomicAdd(&next->sub[sub].counts, ((unsigned long long)n_sh << 32) | (unsigned long long)n_rad);
+    old = __shfl(old, 0);
+    e.rad = (unsigned)old; e.sh = (unsigned)(old >> 32);
     // Reservations at both ends are totally ordered by the single atomic word, so
-    // base + n + other <= sub_capacity means these slots are not, and will never be, claimed
+    // rad + n_rad + sh + n_sh <= sub_capacity means these slots are not, and will never be, claimed
     // from the other end.  Otherwise flag the overflow (the frame is redone with larger queues)
     // and drop the rays.
-    if ((unsigned long long)base + n + other > q.sub_capacity) { if ((int)lane == leader) next->overflow = 1u; return; }
-    if (want) {
-        const unsigned k = base + (unsigned)__popcll(mask & ((1ull << lane) - 1ull));
+    if ((unsigned long long)e.rad + n_rad + e.sh + n_sh > q.sub_capacity) { if (lane_id() == 0u) next->overflow = 1u; return e; }
+    e.ok = true;
+    return e;
+}
+// Store one ray per requesting lane into reserved slots from `first` on; returns the number stored.
+// Must be reached by every lane of the wave.
+RTX_DEV unsigned emit(const Queue& q, unsigned sub, const Emit& e, unsigned first, bool shadow, bool want, V3 o, V3 d, V3 w, double aux,
+                      unsigned pixel, unsigned meta) {
+    const unsigned long long mask = __ballot(want);
+    if (want && e.ok) {
+        const unsigned k = first + (unsigned)__popcll(mask & ((1ull << lane_id()) - 1ull));
         const unsigned idx = sub * q.sub_capacity + (shadow ? q.sub_capacity - 1u - k : k);
         RTX_GLOBAL Ray* r = (RTX_GLOBAL Ray*)q.rays + idx;
         r->o[0] = o.x; r->o[1] = o.y; r->o[2] = o.z;
@@ -1139,6 +1148,7 @@ RTX_DEV void emit(const Queue& q, GenCtrl* next, unsigned sub, bool shadow, bool
         r->w[0] = w.x; r->w[1] = w.y; r->w[2] = w.z;
         r->aux = aux; r->pixel = pixel; r->meta = meta;
     }
+    return (unsigned)__popcll(mask);
 }
 
 // The rays one generation received, as a list of work items: all radiance rays (sub-queue
@@ -2115,7 +2125,7 @@ k_trace(const Launch* __restrict__ Lp, GenCtrl* ctrl, const int gen, double* __r
     __syncthreads();
 #if RTX_WAVE_TALLY
     const long long clk_begin_all = RTX_TICK();
-    long long clk_drained = clk_begin_all, clk_wide_saving = 0, clk_wide = 0, clk_steps = 0, clk_service = 0, clk_lane = 0;
+    long long clk_drained = clk_begin_all, clk_wide_saving = 0, clk_wide = 0, clk_steps = 0, clk_service = 0, clk_lane = 0, clk_claim = 0;
     unsigned n_wide_jobs = 0, n_passes = 0;
     WideOut wl = {};
 #endif
@@ -2170,8 +2180,14 @@ k_trace(const Launch* __restrict__ Lp, GenCtrl* ctrl, const int gen, double* __r
                     if (chunk_next == chunk_end) {
                         unsigned base = n_in;
                         if (static_end < n_in) {
+#if RTX_WAVE_TALLY
+                            const long long a0 = RTX_TICK();
+#endif
                             if (lane == 0) base = static_end + atomicAdd(&me->head_trace, chunk);
                             base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
+#if RTX_WAVE_TALLY
+                            clk_claim += RTX_TICK() - a0;
+#endif
                         }
                         if (base >= n_in) {
                             drained = true; chunk_next = chunk_end = 0;
@@ -2266,7 +2282,7 @@ k_trace(const Launch* __restrict__ Lp, GenCtrl* ctrl, const int gen, double* __r
         atomicAdd((unsigned long long*)&me->tally[8], life);
         // the longest wave and what it spent its time on: lifetime in units of 64 ticks, then per cent of it
         // in wave-wide jobs, in traversal steps and in service passes, then its numbers of wave-wide jobs and of service passes
-        atomicMax((unsigned long long*)&me->tally[10], ((life >> 6) << 38) | ((unsigned long long)(clk_wide * 100 / (long long)life) << 31) |
+        atomicMax((unsigned long long*)&me->tally[10], ((life >> 6) << 38) | ((unsigned long long)((RTX_WAVE_TALLY == 2 ? clk_claim : clk_wide) * 100 / (long long)life) << 31) |
                   ((unsigned long long)((RTX_WAVE_TALLY == 2 ? clk_lane : clk_steps) * 100 / (long long)life) << 24) | ((unsigned long long)(clk_service * 100 / (long long)life) << 17) |
                   ((unsigned long long)(n_wide_jobs > 255u ? 255u : n_wide_jobs) << 9) | (n_passes > 511u ? 511u : n_passes));
         atomicAdd(&me->tally[12], 1u);
@@ -2485,6 +2501,9 @@ k_shade(const Launch* __restrict__ Lp, GenCtrl* ctrl, const int gen, double* __r
         // Light loop: one shadow ray per light for conductor and plain materials, carrying the
         // unshadowed contribution (utils.cpp:887-913, 1008-1038); isInShadow: utils.cpp:1066-1084.
         const bool lit = shade && mtype != RTX_MAT_DIELECTRIC;
+        const unsigned n_lit = (unsigned)__popcll(__ballot(lit));
+        const Emit em = emit_reserve(qout, next, my_sub, (unsigned)__popcll(__ballot(c0)) + (unsigned)__popcll(__ballot(c1)),
+                                     n_lit * (unsigned)S.n_lights);
         for (int li = 0; li < S.n_lights; li++) {
             V3 so = P, sd = d, sw = W;
             double dist_to_light = 0.0;
@@ -2510,10 +2529,10 @@ k_shade(const Launch* __restrict__ Lp, GenCtrl* ctrl, const int gen, double* __r
                 sw = vmul(W, contrib);
                 dist_to_light = sqrt(dot(vsub(lp, P), vsub(lp, P)));
             }
-            emit(qout, next, my_sub, true, lit, so, sd, sw, dist_to_light, pixel, 0u);
+            emit(qout, my_sub, em, em.sh + (unsigned)li * n_lit, true, lit, so, sd, sw, dist_to_light, pixel, 0u);
         }
-        emit(qout, next, my_sub, false, c0, c0o, c0d, c0w, 0.0, pixel, RTX_META(depth + 1, -1));
-        emit(qout, next, my_sub, false, c1, c1o, c1d, c1w, 0.0, pixel, RTX_META(depth + 1, c1beer));
+        const unsigned n_c0 = emit(qout, my_sub, em, em.rad, false, c0, c0o, c0d, c0w, 0.0, pixel, RTX_META(depth + 1, -1));
+        emit(qout, my_sub, em, em.rad + n_c0, false, c1, c1o, c1d, c1w, 0.0, pixel, RTX_META(depth + 1, c1beer));
     }
 }
 
