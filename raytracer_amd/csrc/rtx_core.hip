@@ -998,19 +998,13 @@ int render_frame(rtx_scene* sc, const rtx_camera* cam, int32_t tw, int32_t th, i
                 const unsigned long long mx = (packed >> 38) << 6;
                 const unsigned n = ctrl[gen].tally[12];
                 if (n) fprintf(stderr, "[rtx] gen %d: %u waves, mean lifetime %.1f us, longest %.1f us (at 2.4 GHz; %u %% of it in %u wave-wide jobs, %u %% in traversal steps, %u %% in %u service passes): filled %.0f %%; "
-                               "waves by lifetime in 150 us bins: %u %u %u %u %u %u %u+; longest with wide jobs side by side %.1f us; after the queue ran dry: mean %.1f us, longest %.1f us\n", gen, n,
+                               "waves by lifetime in 150 us bins: %u %u %u %u %u %u %u %u+; after the queue ran dry: mean %.1f us, longest %.1f us\n", gen, n,
                                (double)sum / n / 2400.0, (double)mx / 2400.0, (unsigned)(packed >> 31) & 127u, (unsigned)(packed >> 9) & 255u,
                                (unsigned)(packed >> 24) & 127u, (unsigned)(packed >> 17) & 127u, (unsigned)packed & 511u, 100.0 * (double)sum / n / (double)mx,
                                ctrl[gen].tally[0], ctrl[gen].tally[1], ctrl[gen].tally[2], ctrl[gen].tally[3], ctrl[gen].tally[4],
-                               ctrl[gen].tally[5], ctrl[gen].tally[6], (double)(ctrl[gen].tally[7] & 0x7FFFFFFFu) * 256.0 / 2400.0,
+                               ctrl[gen].tally[5], ctrl[gen].tally[6], ctrl[gen].tally[7],
                                (double)*(const unsigned long long*)&ctrl[gen].tally[14] / n / 2400.0, (double)ctrl[gen].tally[13] * 256.0 / 2400.0);
             }
-        if (gen_timing && RTX_WAVE_TALLY == 3)
-            for (int gen = 0; gen < G; gen++)
-                fprintf(stderr, "[rtx] gen %d: the longest wave's longest wave-wide job: frontier set up %.1f us, entries taken %.1f us, records loaded %.1f us; "
-                        "the rest of a job's steps, at most %.1f us\n", gen, (double)(*(const unsigned long long*)&ctrl[gen].tally[0] & 0x3FFFFFFFFFull) / 2400.0,
-                        (double)(*(const unsigned long long*)&ctrl[gen].tally[2] & 0x3FFFFFFFFFull) / 2400.0,
-                        (double)(*(const unsigned long long*)&ctrl[gen].tally[4] & 0x3FFFFFFFFFull) / 2400.0, (double)ctrl[gen].tally[6] / 2400.0);
         if (gen_timing && RTX_SEARCH_TALLY)
             fprintf(stderr, "[rtx] search: instance jobs ended %u (with a hit %u), instances met by the walk %u, walks ended %u (with a k %u), "
                     "probe jobs ended %u (found %u), probes tried %u\n", ctrl[0].tally[0], ctrl[0].tally[1], ctrl[0].tally[2], ctrl[0].tally[3],

@@ -1499,7 +1499,7 @@ RTX_DEV void small_prefix(const int v, int& excl, int& total) {
 // What the wave needs of the owner's lane, and what it hands back.  Passed by value: the function is
 // not inlined (inlined, its registers spoil the allocation of the traversal loop around the call).
 struct WideIn { double rox, roy, roz, rdx, rdy, rdz, ix, iy, iz, t_min, stop; int par, shadow, sp, cur_ref, cur_cnt; v4i top; };
-struct WideOut { double t_min; int btri, wmin, wmax, steps; unsigned t_seed, t_pop, t_load, t_rest; unsigned long long sel; };
+struct WideOut { double t_min; int btri, wmin, wmax; unsigned long long sel; };
 
 // The jobs of the lanes in `m` (at most RTX_WIDE_JOBS, their stacks together within the frontier's
 // room: the caller sees to both), traversed by the whole wave *side by side*: one frontier holds the
@@ -1756,8 +1756,7 @@ __device__ __attribute__((noinline)) WideOut wide_multi(const Scene& S, const Wa
 #endif
     // every owner's result: smallest t, then first in the reference's visiting order
     WideOut out;
-    out.t_min = INFINITY; out.btri = -1; out.wmin = INT_MAX; out.wmax = -1; out.steps = 0;
-    out.t_seed = out.t_pop = out.t_load = out.t_rest = 0; out.sel = m;
+    out.t_min = INFINITY; out.btri = -1; out.wmin = INT_MAX; out.wmax = -1; out.sel = m;
     if (mine) {
         const lds_double* t = T + 16 * my_slot;
         const double bk_d = t[12], tr = t[14], r = t[15];
@@ -1769,15 +1768,14 @@ __device__ __attribute__((noinline)) WideOut wide_multi(const Scene& S, const Wa
 }
 
 // Run the jobs of the lanes in `m` wave-wide, as many at a time as wide_multi takes.
-RTX_DEV WideOut wide_jobs(const Scene& S, const Wave& wv, Lane& L, glob_v4i* stk, unsigned* inst_bits,
-                          unsigned long long m) {
+RTX_DEV void wide_jobs(const Scene& S, const Wave& wv, Lane& L, glob_v4i* stk, unsigned* inst_bits,
+                       unsigned long long m) {
     WideIn in;
     in.rox = L.ro.x; in.roy = L.ro.y; in.roz = L.ro.z; in.rdx = L.rd.x; in.rdy = L.rd.y; in.rdz = L.rd.z;
     in.ix = L.ix; in.iy = L.iy; in.iz = L.iz; in.t_min = L.t_min; in.stop = L.orig_t_min;
     in.par = L.par; in.shadow = L.is_shadow; in.sp = L.sp; in.cur_ref = L.cur_ref; in.cur_cnt = L.cur_cnt; in.top = L.top;
-    WideOut out = {};
     while (m != 0ull) {
-        out = wide_multi(S, wv, in, stk, inst_bits, m);
+        const WideOut out = wide_multi(S, wv, in, stk, inst_bits, m);
         const unsigned long long sel = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(out.sel >> 32)) << 32) |
                                        (unsigned)__builtin_amdgcn_readfirstlane((int)out.sel);
         m &= ~sel;
@@ -1788,7 +1786,6 @@ RTX_DEV WideOut wide_jobs(const Scene& S, const Wave& wv, Lane& L, glob_v4i* stk
             L.state = LS_JOB_DONE;
         }
     }
-    return out;
 }
 
 // NEST (1: consistent mode, 2: exact mode's search): instances are not collected for a replay in
@@ -2125,9 +2122,8 @@ k_trace(const Launch* __restrict__ Lp, GenCtrl* ctrl, const int gen, double* __r
     __syncthreads();
 #if RTX_WAVE_TALLY
     const long long clk_begin_all = RTX_TICK();
-    long long clk_drained = clk_begin_all, clk_wide_saving = 0, clk_wide = 0, clk_steps = 0, clk_service = 0, clk_lane = 0, clk_claim = 0;
+    long long clk_drained = clk_begin_all, clk_wide = 0, clk_steps = 0, clk_service = 0, clk_lane = 0, clk_claim = 0;
     unsigned n_wide_jobs = 0, n_passes = 0;
-    WideOut wl = {};
 #endif
     Tally tl = {};
     unsigned n_records = 0;                      // records this wave fetches (wave-uniform; a wave stays far below 2^32)
@@ -2244,7 +2240,7 @@ k_trace(const Launch* __restrict__ Lp, GenCtrl* ctrl, const int gen, double* __r
             }
             if (COUNT) { tl.clk_serv += (unsigned long long)(clock64() - c0); tl.passes++; }
 #if RTX_WAVE_TALLY
-            clk_service += RTX_TICK() - s0; if (RTX_WAVE_TALLY != 3) n_passes++;
+            clk_service += RTX_TICK() - s0; n_passes++;
 #endif
             continue;
         }
@@ -2258,18 +2254,9 @@ k_trace(const Launch* __restrict__ Lp, GenCtrl* ctrl, const int gen, double* __r
         const long long w0 = RTX_TICK();
         clk_steps += w0 - t0;
 #endif
-        WideOut wide_longest = {};
-        if (!COUNT && WIDE != 0 && m_wide != 0ull) wide_longest = wide_jobs(S, wv, L, stk, inst_bits, m_wide);
-        (void)wide_longest;
+        if (!COUNT && WIDE != 0 && m_wide != 0ull) wide_jobs(S, wv, L, stk, inst_bits, m_wide);
 #if RTX_WAVE_TALLY
-        if (m_wide != 0ull) {          // what running these jobs side by side instead of one after the other could save at most
-            const long long n = __popcll(m_wide);
-            clk_wide_saving += (RTX_TICK() - w0) * (n - 1) / n;
-            clk_wide += RTX_TICK() - w0; n_wide_jobs += (unsigned)n;
-            if (RTX_WAVE_TALLY == 3 && (unsigned)wide_longest.steps > n_passes) {       // (the longest job's steps instead of the passes)
-                n_passes = (unsigned)wide_longest.steps; wl = wide_longest;
-            }
-        }
+        if (m_wide != 0ull) { clk_wide += RTX_TICK() - w0; n_wide_jobs += (unsigned)__popcll(m_wide); }
 #endif
         if (COUNT) tl.clk_trav += (unsigned long long)(clock64() - c1);
     }
@@ -2281,25 +2268,18 @@ k_trace(const Launch* __restrict__ Lp, GenCtrl* ctrl, const int gen, double* __r
         const unsigned long long life = (unsigned long long)(RTX_TICK() - clk_begin_all);
         atomicAdd((unsigned long long*)&me->tally[8], life);
         // the longest wave and what it spent its time on: lifetime in units of 64 ticks, then per cent of it
-        // in wave-wide jobs, in traversal steps and in service passes, then its numbers of wave-wide jobs and of service passes
+        // in wave-wide jobs, in traversal steps and in service passes, then its numbers of wave-wide jobs and of
+        // service passes (RTX_WAVE_TALLY=2: in claims and in the lanes' service instead of the first two)
         atomicMax((unsigned long long*)&me->tally[10], ((life >> 6) << 38) | ((unsigned long long)((RTX_WAVE_TALLY == 2 ? clk_claim : clk_wide) * 100 / (long long)life) << 31) |
                   ((unsigned long long)((RTX_WAVE_TALLY == 2 ? clk_lane : clk_steps) * 100 / (long long)life) << 24) | ((unsigned long long)(clk_service * 100 / (long long)life) << 17) |
                   ((unsigned long long)(n_wide_jobs > 255u ? 255u : n_wide_jobs) << 9) | (n_passes > 511u ? 511u : n_passes));
         atomicAdd(&me->tally[12], 1u);
         const unsigned bin = (unsigned)(life / (150ull * 2400ull));          // 150 us bins at 2.4 GHz
-        if (RTX_WAVE_TALLY != 3) atomicAdd(&me->tally[bin < 6u ? bin : 6u], 1u);
-        else {      // instead of the bins: where the longest wave's longest wave-wide job spent its ticks (keyed by the lifetime)
-            atomicMax((unsigned long long*)&me->tally[0], ((life >> 6) << 38) | wl.t_seed);
-            atomicMax((unsigned long long*)&me->tally[2], ((life >> 6) << 38) | wl.t_pop);
-            atomicMax((unsigned long long*)&me->tally[4], ((life >> 6) << 38) | wl.t_load);
-            if (wl.t_rest) atomicMax(&me->tally[6], wl.t_rest);         // (not keyed: the longest anywhere)
-        }
+        atomicAdd(&me->tally[bin < 7u ? bin : 7u], 1u);
         // ... and how long the wave went on after it found the queue dry (sum and maximum)
         const unsigned long long after = (unsigned long long)(RTX_TICK() - clk_drained);
         atomicAdd((unsigned long long*)&me->tally[14], after);
         atomicMax(&me->tally[13], (unsigned)(after >> 8));
-        // the longest lifetime if wave-wide jobs of one wave ran side by side (tally[7], units of 256 ticks, replaces the last bin)
-        atomicMax(&me->tally[7], (unsigned)((life - (unsigned long long)clk_wide_saving) >> 8) | 0x80000000u);
     }
 #endif
     if (COUNT && counters) {
