@@ -1417,13 +1417,13 @@ RTX_DEV void cand_swap(Cand& a, Cand& b, bool doit) {
     b.e = doit ? x.e : y.e; b.ref = doit ? x.ref : y.ref; b.cnt = doit ? x.cnt : y.cnt; b.ok = doit ? x.ok : y.ok;
 }
 
-// ---- one lane's job, traversed by the whole wave ------------------------------------------
+// ---- the last jobs of a wave, traversed by the whole wave ----------------------------------
 //
 // When a generation has drained, what is left of it is a handful of long rays, each a chain of
 // several hundred dependent steps in an otherwise idle wave; the kernel's duration is that
-// chain.  Here the wave's 64 lanes work through the *frontier* of one such job instead: every
+// chain.  Here the wave's 64 lanes work through the *frontier* of such jobs instead: every
 // lane takes one open node, tests it, and puts the children that pass back (a LIFO frontier in
-// the wave's LDS rows, so the order stays close to depth-first and the bound tightens early).
+// the wave's LDS rows, so the order stays close to depth-first and the bounds tighten early).
 //
 // The result is the reference's.  bvh.cpp:104-185 returns the triangle with the smallest t
 // below the incoming bound, ties going to the one it visits first (strict `t < t_min`).  A node
@@ -2076,13 +2076,15 @@ RTX_DEV unsigned long long traverse_steps(const Scene& S, const Wave& wv, Lane& 
     return 0ull;
 }
 
-// WIDE = 2: the variant for generations of at most RTX_WIDE_MAX_RAYS rays, all of whose last
-// jobs are traversed wave-wide (wide_job).  It and a main variant are launched for every
-// generation and exactly one of them does the work; the other returns at once.
-// WIDE = 1: main variant in which drained waves finish their long-running jobs wave-wide too.
+// WIDE = 1: main variant in which drained waves finish their jobs wave-wide (wide_multi): those that
+// have run RTX_WIDE_AGE steps once at most RTX_WIDE_LANES are left, and every job from its first step in
+// generations of at most RTX_WIDE_MAX_RAYS rays.
 // WIDE = 0: main variant without any of it.  (Variants rather than branches: the mere presence
 // of the call changes the register allocation of the code around it -- the service passes pay
 // for it, which scenes dominated by instance replay notice -- so the host picks per scene.)
+// WIDE = 2: launched beside a WIDE = 0 main variant, for generations of at most RTX_WIDE_MAX_RAYS
+// rays, all of whose jobs it traverses wave-wide; exactly one of the two does the work, the other
+// returns at once.
 template <bool COUNT, int WIDE, bool FAST, int NEST = 0>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RTX_TRACE_WAVES, RTX_TRACE_WAVES)))
 k_trace(const Launch* __restrict__ Lp, GenCtrl* ctrl, const int gen, double* __restrict__ accum,
