@@ -1838,6 +1838,9 @@ RTX_DEV unsigned long long traverse_steps(const Scene& S, const Wave& wv, Lane& 
         // longest rays of a generation); it loads the records directly, one memory round trip
         // without the detour through LDS.  Otherwise the wave fetches cooperatively.
         const long long f0 = COUNT ? clock64() : 0;
+#if RTX_WAVE_TALLY == 3
+        const long long k_f0 = RTX_TICK();
+#endif
         double rec[32];
         const bool wants = in_job && !(NEST && L.cur_cnt == -1);      // (a lane that only asks for a pop fetches nothing)
         // NEST: a lane whose entry is an instance fetches the set-up half of that instance's object record
@@ -1857,6 +1860,10 @@ RTX_DEV unsigned long long traverse_steps(const Scene& S, const Wave& wv, Lane& 
             __builtin_amdgcn_wave_barrier();
         }
         if (COUNT) tl.clk_fetch += (unsigned long long)(clock64() - f0);
+#if RTX_WAVE_TALLY == 3
+        const long long k_f1 = RTX_TICK();
+        tl.clk_fetch += (unsigned long long)(k_f1 - k_f0);
+#endif
 
         bool need_pop = false;
         // the walk of the TLAS in NEST mode compares with a bound a hair above the current one: an
@@ -2005,6 +2012,9 @@ RTX_DEV unsigned long long traverse_steps(const Scene& S, const Wave& wv, Lane& 
         }
         __builtin_amdgcn_wave_barrier();
         const long long p0 = COUNT ? clock64() : 0;
+#if RTX_WAVE_TALLY == 3
+        const long long k_p0 = RTX_TICK();
+#endif
         int base = 0;                  // entries below belong to the suspended walk
         double t_pop = 0.0;            // (the leaf tests may have pulled the bound in)
         if (NEST) { base = (nl && L.obj != -1) ? L.word : 0; t_pop = (nl && L.obj == -1) ? L.t_min * 1.000001 : L.t_min; }
@@ -2072,6 +2082,9 @@ RTX_DEV unsigned long long traverse_steps(const Scene& S, const Wave& wv, Lane& 
             }
         }
         if (COUNT) tl.clk_pop += (unsigned long long)(clock64() - p0);
+#if RTX_WAVE_TALLY == 3
+        { const long long k_e = RTX_TICK(); tl.clk_pop += (unsigned long long)(k_e - k_p0); tl.clk_trav += (unsigned long long)(k_p0 - k_f1); tl.passes++; }
+#endif
     }
     return 0ull;
 }
@@ -2272,6 +2285,9 @@ k_trace(const Launch* __restrict__ Lp, GenCtrl* ctrl, const int gen, double* __r
         // the longest wave and what it spent its time on: lifetime in units of 64 ticks, then per cent of it
         // in wave-wide jobs, in traversal steps and in service passes, then its numbers of wave-wide jobs and of
         // service passes (RTX_WAVE_TALLY=2: in claims and in the lanes' service instead of the first two)
+        if (RTX_WAVE_TALLY == 3) {      // the traversal steps' sections instead: record fetch, tests, stack; steps / 8
+            clk_wide = (long long)tl.clk_fetch; clk_steps = (long long)tl.clk_trav; clk_service = (long long)tl.clk_pop; n_passes = tl.passes >> 3;
+        }
         atomicMax((unsigned long long*)&me->tally[10], ((life >> 6) << 38) | ((unsigned long long)((RTX_WAVE_TALLY == 2 ? clk_claim : clk_wide) * 100 / (long long)life) << 31) |
                   ((unsigned long long)((RTX_WAVE_TALLY == 2 ? clk_lane : clk_steps) * 100 / (long long)life) << 24) | ((unsigned long long)(clk_service * 100 / (long long)life) << 17) |
                   ((unsigned long long)(n_wide_jobs > 255u ? 255u : n_wide_jobs) << 9) | (n_passes > 511u ? 511u : n_passes));
