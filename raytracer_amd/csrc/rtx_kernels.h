@@ -97,14 +97,17 @@ struct Rec {
 };
 
 // Per-ray slab constants: 1/d per axis (bvh.cpp:43 computes it per node; the quotient is the
-// same value) and the "parallel" predicate |d| < 1e-9f (bvh.cpp:36).
+// same value) and, in `par`, bits 0-2 the "parallel" predicate |d| < 1e-9f per axis (bvh.cpp:36) and
+// bits 4-6 "the far child comes first at a split along this axis", !(d >= 0) (bvh.cpp:139-147).
 struct Slab { double ox, oy, oz, ix, iy, iz; int par; };
+#define RTX_PAR_AXES 7
 
 RTX_DEV Slab make_slab(V3 o, V3 d) {
     Slab s;
     s.ox = o.x; s.oy = o.y; s.oz = o.z;
     const double eps = (double)1e-9f;
-    s.par = (fabs(d.x) < eps ? 1 : 0) | (fabs(d.y) < eps ? 2 : 0) | (fabs(d.z) < eps ? 4 : 0);
+    s.par = (fabs(d.x) < eps ? 1 : 0) | (fabs(d.y) < eps ? 2 : 0) | (fabs(d.z) < eps ? 4 : 0) |
+            (!(d.x >= 0.0) ? 16 : 0) | (!(d.y >= 0.0) ? 32 : 0) | (!(d.z >= 0.0) ? 64 : 0);
     s.ix = 1.0 / d.x; s.iy = 1.0 / d.y; s.iz = 1.0 / d.z;
     return s;
 }
@@ -114,7 +117,7 @@ RTX_DEV Slab make_slab(V3 o, V3 d) {
 // bound t_min exactly when t_min >= enter (t1 = min(t_min, exits) >= t0).
 RTX_DEV bool box_enter(const double* mn, const double* mx, const Slab& s, double& enter) {
     double t0 = 0.0, t1 = INFINITY;
-    if (s.par) {
+    if (s.par & RTX_PAR_AXES) {
         if ((s.par & 1) && (s.ox < mn[0] || s.ox > mx[0])) return false;
         if ((s.par & 2) && (s.oy < mn[1] || s.oy > mx[1])) return false;
         if ((s.par & 4) && (s.oz < mn[2] || s.oz > mx[2])) return false;
@@ -1831,7 +1834,9 @@ RTX_DEV unsigned long long traverse_steps(const Scene& S, const Wave& wv, Lane& 
         }
         // rays with an axis-parallel component are rare: the wave takes the general box test
         // only when one of its traversing lanes has one
-        const bool any_par = __ballot(in_job && L.par != 0) != 0ull;
+        const bool any_par = __ballot(in_job && (L.par & RTX_PAR_AXES) != 0) != 0ull;
+        // ... and looks for instance slots only when one of them walks the TLAS (object -1)
+        const bool any_walk = __ballot(in_job && L.obj == -1) != 0ull;
 
         // The lane's 256-byte record: a collapsed node, or two consecutive triangle records.
         // A wave with only a lane or two still traversing is on the frame's critical path (the
@@ -1856,7 +1861,10 @@ RTX_DEV unsigned long long traverse_steps(const Scene& S, const Wave& wv, Lane& 
             }
         } else {
             coop_fetch(wv, wants ? key : -1, blas);
-            if (wants) row_read<0, 16>(wv, rec);
+            // (every lane reads its row, whether it asked for a record or not: a read under the
+            // lanes' own condition makes the compiler keep the other lanes' thirty-two registers
+            // alive through it, sixty register moves a step)
+            row_read<0, 16>(wv, rec);
             __builtin_amdgcn_wave_barrier();
         }
         if (COUNT) tl.clk_fetch += (unsigned long long)(clock64() - f0);
@@ -1940,7 +1948,7 @@ RTX_DEV unsigned long long traverse_steps(const Scene& S, const Wave& wv, Lane& 
                     c[k].e = e;
                     const bool pass = hit & ((NEST ? t_cmp : L.t_min) >= e);
                     c[k].ok = pass & (c[k].cnt >= 0 || (NEST && nl && c[k].cnt == -2));
-                    if ((!NEST || !nl) && pass && c[k].cnt == -2) {
+                    if (any_walk && (!NEST || !nl) && pass && c[k].cnt == -2) {
                         // TLAS walk: the slot is a mesh instance whose world box the ray can meet
                         const int w = c[k].ref >> 5;
                         atomicOr(inst_bits + n_summary + w, 1u << (c[k].ref & 31));
@@ -1952,31 +1960,35 @@ RTX_DEV unsigned long long traverse_steps(const Scene& S, const Wave& wv, Lane& 
                 // left iff dir[splitAxis] >= 0 (bvh.cpp:139-147).  Slots 0,1 hang under the left
                 // child (split axisL), slots 2,3 under the right child (axisR), the two pairs
                 // under the node itself (axis0).
+                // (the direction's sign per axis is kept in the lane's `par` word: a shift and a mask per split)
                 const int axis0 = __double2loint(nd[28]), axisL = __double2hiint(nd[28]), axisR = __double2loint(nd[29]);
-                const double d0 = axis0 == 0 ? L.rd.x : (axis0 == 1 ? L.rd.y : L.rd.z);
-                const double dl = axisL == 0 ? L.rd.x : (axisL == 1 ? L.rd.y : L.rd.z);
-                const double dr = axisR == 0 ? L.rd.x : (axisR == 1 ? L.rd.y : L.rd.z);
+                const unsigned far_first = (unsigned)L.par >> 4;
                 // a leaf child occupies the first slot of its pair: nothing to order there
-                cand_swap(c[0], c[1], !(dl >= 0.0) && (NEST ? c[1].cnt != -1 : c[1].cnt >= 0));
-                cand_swap(c[2], c[3], !(dr >= 0.0) && (NEST ? c[3].cnt != -1 : c[3].cnt >= 0));
-                const bool right_first = !(d0 >= 0.0);
+                cand_swap(c[0], c[1], ((far_first >> axisL) & 1u) && (NEST ? c[1].cnt != -1 : c[1].cnt >= 0));
+                cand_swap(c[2], c[3], ((far_first >> axisR) & 1u) && (NEST ? c[3].cnt != -1 : c[3].cnt >= 0));
+                const bool right_first = ((far_first >> axis0) & 1u) != 0u;
                 cand_swap(c[0], c[2], right_first);
                 cand_swap(c[1], c[3], right_first);
                 // c[0..3] is now near -> far.  The nearest passing child is entered; the others
                 // are pushed, farthest first, each with its entry distance for the re-check at pop.
                 const bool any0 = c[0].ok, any1 = any0 | c[1].ok, any2 = any1 | c[2].ok;
+                // Room for the three entries a step can push is checked once.  (The host accepts a tree
+                // only if three entries per record level fit, so a lane is never short of room; if it
+                // is after all, the frame is reported as failed instead of silently losing a subtree.)
+                const bool room = L.sp + 3 <= (NEST == 2 ? RTX_SEARCH_STACK : RTX_STACK);
+                bool lost = false;
 #pragma unroll
                 for (int k = 3; k >= 1; k--) {
                     const bool earlier = k == 3 ? any2 : (k == 2 ? any1 : any0);
-                    // (a full stack cannot happen with trees the host has accepted; if it does, the
-                    // frame is reported as failed instead of silently losing a subtree)
-                    if (c[k].ok && earlier && L.sp >= (NEST == 2 ? RTX_SEARCH_STACK : RTX_STACK)) *S.limit_flag = 1u;
-                    if (c[k].ok && earlier && L.sp < (NEST == 2 ? RTX_SEARCH_STACK : RTX_STACK)) {
+                    const bool want = c[k].ok && earlier;
+                    lost |= want && !room;
+                    if (want && room) {
                         if (L.sp > 0) stk[L.sp - 1] = L.top;
                         L.top.x = __double2loint(c[k].e); L.top.y = __double2hiint(c[k].e); L.top.z = c[k].ref; L.top.w = c[k].cnt;
                         L.sp++;
                     }
                 }
+                if (lost) *S.limit_flag = 1u;
                 if (any2 | c[3].ok) {
                     const int sel = any0 ? 0 : (c[1].ok ? 1 : (c[2].ok ? 2 : 3));
                     L.cur_ref = sel == 0 ? c[0].ref : (sel == 1 ? c[1].ref : (sel == 2 ? c[2].ref : c[3].ref));
