@@ -15,8 +15,9 @@ rank 0's JSON line and exits with the first failing rank's code.  Under torchrun
 
 Workloads and how they shard (the scene is replicated on every GPU, no ray leaves its GPU):
   dragon_metal (default), marching_dragons, metal_glass_plates, grass_desert, mode frames:
-      rank r renders frame r of an orbit around the scene every step -- whole frames, no
-      collective on the data path (weak scaling).
+      the K timed steps are a K-frame turntable around the scene (frame 0 = the scene file's own
+      camera); every rank renders each frame once, rank r starting r/N of the way round -- whole
+      frames, no collective on the data path, the same work per GPU at every N (weak scaling).
   camera_around_david: the 360-frame sequence itself; rank r renders frames r, r+N, ... through
       the animation pipeline (HostScene.load_next keeps the geometry, update_lights); one step
       = one frame per rank (weak scaling).
@@ -522,7 +523,14 @@ def measure_static(R: Rank, args, name, mode, steps, warmup, with_cpu, pipelined
     cam0, _ = hs.camera(0)
     tw, th = (int(x) for x in args.tile.split("x"))
     world, rank = R.world, R.rank
-    cam = orbit_camera(cam0, 360.0 * rank / world) if (mode == "frames" and world > 1) else cam0
+    cam = cam0
+    # mode frames: the timed steps are a turntable of `steps` frames around the scene (frame 0 = the
+    # scene file's own camera); every rank renders every frame of it exactly once, rank r starting
+    # r/N of the way round.  The views differ in cost by up to 40 %, so a rank that kept one view
+    # would make the slowest view the measure of every N > 1; this way each GPU does the same work
+    # at every N, which is what weak scaling compares.
+    turntable = [orbit_camera(cam0, 360.0 * j / steps) for j in range(steps)] if mode == "frames" else None
+    phase = (rank * steps) // world
 
     # ---- untimed counting pass: rays and traversal work of this rank's step ----------------
     R.note("device counting pass")
@@ -581,7 +589,7 @@ def measure_static(R: Rank, args, name, mode, steps, warmup, with_cpu, pipelined
         ds.set_consistent(True)
     if mode == "frames":
         def step(i):
-            return ds.render(cam, out=frame)[2]
+            return ds.render(turntable[(i + phase) % steps], out=frame)[2]
     else:
         gatherer = D.TileGatherer(cam.width, cam.height, tw, th, rank, world, device=R.red_dev,
                                   unpack=rt.unpack_tiles, frame=frame)
@@ -608,15 +616,16 @@ def measure_static(R: Rank, args, name, mode, steps, warmup, with_cpu, pipelined
         for d, f in extra:
             d.render(cam, out=f)
 
-        def burst(d, f):
-            for _ in range(steps):
-                d.render(cam, out=f)
+        def burst(d, f, k):
+            # (each pipeline renders the whole turntable once, the pipelines a k-th of the way apart)
+            for i in range(steps):
+                d.render(turntable[(i + phase + (k * steps) // k_fl) % steps], out=f)
         R.barrier()
         t0 = time.perf_counter()
-        threads = [threading.Thread(target=burst, args=(d, f)) for d, f in extra]
+        threads = [threading.Thread(target=burst, args=(d, f, k + 1)) for k, (d, f) in enumerate(extra)]
         for t in threads:
             t.start()
-        burst(ds, frame)
+        burst(ds, frame, 0)
         for t in threads:
             t.join()
         R.barrier()
@@ -628,7 +637,18 @@ def measure_static(R: Rank, args, name, mode, steps, warmup, with_cpu, pipelined
     kernel_ms = sum(s["kernel_ms"] for s in stats)
     trace_ms = sum(s["trace_ms"] for s in stats)
     trace_launches = sum(s["trace_launches"] for s in stats)
-    rays_step, = R.reduce([rays_rank])
+    # rays of the timed frames (rtx_stats counts every frame's rays without device counters)
+    rays_timed_rank = sum(int(s_["rays"]) for s_ in stats)
+    rays_step = R.reduce([rays_timed_rank])[0] / steps
+    rays_frame = rays_timed_rank / steps              # this rank's mean frame
+    # the scene file's own view alone (the frame the CPU reference is timed on and parity is checked on)
+    view0_ms = None
+    if mode == "frames" and with_cpu:
+        ds.render(cam0, out=frame)
+        t0 = time.perf_counter()
+        for _ in range(5):
+            ds.render(cam0, out=frame)
+        view0_ms = (time.perf_counter() - t0) / 5 * 1e3
     out = None
     if rank == 0:
         ms_per_step = elapsed / steps * 1e3
@@ -672,7 +692,7 @@ def measure_static(R: Rank, args, name, mode, steps, warmup, with_cpu, pipelined
             "trace_ms_per_frame": trace_ms / steps, "all_kernels_ms_per_frame": kernel_ms / steps,
             "algorithmic_basis": basis,
             "algorithmic_bytes_per_launch": bytes_per_launch, "algorithmic_bytes_per_frame": alg_b,
-            "algorithmic_bytes_per_ray": alg_b / max(rays_rank, 1),
+            "algorithmic_bytes_per_ray": alg_b / max(rays_frame if basis == "device" else rays_rank, 1),
             "reference_bytes_per_frame": ref_b, "reference_bytes_source": alg_source,
             "device_bytes_per_frame": dev_b,
             "device_bytes_source": "records the trace kernel fetched in the timed frames (rtx_stats.record_fetches, counted in "
@@ -711,11 +731,13 @@ def measure_static(R: Rank, args, name, mode, steps, warmup, with_cpu, pipelined
             "higher_is_better": True, "scaling": "weak" if mode == "frames" else "strong",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": name, "description": descr, "mode": mode,
-                       "sharding": ("whole frames: rank r renders orbit frame r of the scene every step, no collective"
+                       "sharding": (f"whole frames of a {steps}-frame turntable around the scene (frame 0 = the scene file's camera): "
+                                    "every rank renders each frame once, rank r starting r/N of the way round; no collective"
                                     if mode == "frames" else
                                     f"interleaved {tw}x{th} tiles of one frame, one gather to rank 0 per frame"),
                        "resolution": [cam.width, cam.height], "rays_per_step": rays_step,
-                       "rays_per_pixel": rays_rank / (cam.width * cam.height) if mode == "frames" else None,
+                       "rays_per_pixel": rays_frame / (cam.width * cam.height) if mode == "frames" else None,
+                       "rays_scene_view": rays_rank if mode == "frames" else None,
                        "frames_per_step": world if mode == "frames" else 1,
                        "host_load_s": t_load, "scene_upload_s": t_upload,
                        "image_buffer": "host, page-locked, reused (download inside the timed step)",
@@ -732,7 +754,9 @@ def measure_static(R: Rank, args, name, mode, steps, warmup, with_cpu, pipelined
             cb, ref_img = cpu_reference_baseline(path, rays_rank, sample_f)
             if cb is not None:
                 out["cpu_baseline"] = cb
-                out["config"]["speedup_vs_cpu_reference_ms_per_frame"] = cb["ms_per_frame"] / ms_per_step
+                # like for like: the reference's frame is the scene file's own view
+                out["config"]["scene_view_ms_per_frame"] = view0_ms
+                out["config"]["speedup_vs_cpu_reference_ms_per_frame"] = cb["ms_per_frame"] / (view0_ms or ms_per_step)
                 if parity is not None and ref_img is not None and ref_img.shape == parity_rgb.shape:
                     parity["vs_reference_ppm"] = image_delta(parity_rgb, ref_img)
         if parity is not None:

@@ -222,24 +222,38 @@ typedef __attribute__((address_space(1))) v4i glob_v4i;
 // Per-wave context: this wave's 64 LDS rows and the lane number.
 struct Wave { lds_double* rows; unsigned lane; lds_double* ctx; };     // ctx: the lane's five doubles of ObjCache::ctx, as an LDS address
 
-// Wave-cooperative gather of one 256-byte record per requesting lane into that lane's LDS row.
-// `key` names the record by its offset in 128-byte
-// units from `blas` (-1 = no request): a collapsed node, or a pair of triangle records.
+// Wave-cooperative gather of one 256-byte record per requesting lane into an LDS row.
+// `key` names the record by its offset in 128-byte units from `blas`: a collapsed node, or a pair
+// of triangle records.  The requests are COMPACTED: the r-th requesting lane (r = its rank among
+// the requesters) owns row r, and only ceil(n/4) load rounds are issued for n requests.  Returns
+// the row this lane reads afterwards (its rank; lanes without a request get some row too, whose
+// contents mean nothing).
 //
 // Sixteen lanes read one record as sixteen adjacent 16-byte pieces, so one load instruction
 // touches 4 records x 256 contiguous bytes instead of 64 scattered pieces.  The loads are
 // LDS-DMA (global_load_lds_dwordx4, destination = wave-uniform base + 16*lane): in round g
-// lane l serves owner 4g + l/16, and the round fills the rows of owners 4g..4g+3.  The lanes
-// learn their owners' keys through the (still unused) row memory: owner w stores its key at
-// dword (w & 3)*16 + (w >> 2), so the sixteen keys a lane needs are 64 contiguous bytes.
+// lane l serves row 4g + l/16, and the round fills rows 4g..4g+3.  The lanes learn the rows'
+// keys through the (still unused) row memory: the owner of row w stores its key at dword
+// (w & 3)*16 + (w >> 2), so the sixteen keys a lane needs are 64 contiguous bytes.  Before that
+// every slot is preset with the first requester's key (two LDS writes of one wave take effect in
+// order): the last round's unused rows then fetch a record that is on its way anyway, and no load
+// needs a per-lane condition -- a round costs four instructions, and the rounds beyond the last
+// request are skipped by scalar branches.
 // To keep the owners' later 16-byte row reads free of bank conflicts the pieces are stored
-// XOR-swizzled: slot s of owner w holds piece s ^ (w & 15) -- applied to the *source* address
+// XOR-swizzled: slot s of row w holds piece s ^ (w & 15) -- applied to the *source* address
 // here and to the slot index in row_read.  Must be executed by every lane of the wave.
 typedef __attribute__((address_space(3))) int lds_int;
 typedef __attribute__((address_space(3))) v4i lds_v4i;
-RTX_DEV void coop_fetch(const Wave& wv, int key, const char* __restrict__ blas) {
+RTX_DEV unsigned coop_fetch(const Wave& wv, const bool wants, const int key, const char* __restrict__ blas) {
     const unsigned lane = wv.lane, quarter = lane >> 4, slot = lane & 15u;
-    ((lds_int*)wv.rows)[(lane & 3u) * 16u + (lane >> 2)] = key;
+    const unsigned long long m_req = __ballot(wants);
+    const unsigned lo = (unsigned)m_req, hi = (unsigned)(m_req >> 32);
+    const unsigned rank = __builtin_amdgcn_mbcnt_hi(hi, __builtin_amdgcn_mbcnt_lo(lo, 0u));
+    const int n_req = __popcll(m_req);
+    if (n_req == 0) return rank;
+    const int key0 = __builtin_amdgcn_readlane(key, (int)__builtin_ctzll(m_req));
+    ((lds_int*)wv.rows)[(lane & 3u) * 16u + (lane >> 2)] = key0;
+    if (wants) ((lds_int*)wv.rows)[(rank & 3u) * 16u + (rank >> 2)] = key;
     __builtin_amdgcn_wave_barrier();
     int okeys[16];
     {
@@ -268,30 +282,27 @@ RTX_DEV void coop_fetch(const Wave& wv, int key, const char* __restrict__ blas) 
     for (int j = 0; j < 4; j++) base[j] = (unsigned long long)blas + (((slot ^ quarter) ^ (4u * j)) << 4);
 #pragma unroll
     for (int g = 0; g < 16; g++) {
-        // (a round none of whose four owners requests anything has no lane to execute it)
-        const int okey = okeys[g];
-        if (okey != -1) {
-            const unsigned long long gp = base[g & 3] + (unsigned long long)(unsigned)okey * unit;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gp,
-                                             (__attribute__((address_space(3))) void*)(size_t)(rows_at + (unsigned)g * (4u * RTX_ROW_DOUBLES * 8u)),
-                                             16, 0, 0);
-        }
+        if (4 * g >= n_req) break;               // (wave-uniform: a scalar branch to the end)
+        const unsigned long long gp = base[g & 3] + (unsigned long long)(unsigned)okeys[g] * unit;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gp,
+                                         (__attribute__((address_space(3))) void*)(size_t)(rows_at + (unsigned)g * (4u * RTX_ROW_DOUBLES * 8u)),
+                                         16, 0, 0);
     }
     // vmcnt(0), as a builtin rather than inline assembly so that the compiler's own wait-count
     // bookkeeping knows that nothing is outstanding after it (gfx9 encoding: vmcnt bits 3:0 and
     // 15:14 zero, expcnt 6:4 and lgkmcnt 11:8 left at "no wait")
     __builtin_amdgcn_s_waitcnt(0x0F70);
     __builtin_amdgcn_wave_barrier();
+    return rank;
 }
 
-// Read pieces FIRST .. FIRST+N-1 of this lane's row (undoing the swizzle) into out[0 .. 2N).
-// The rows are 256-byte aligned, so the address of piece p is (row | swizzle << 4) ^ (p << 4): one
-// XOR per read from a single register.  That register is made opaque on every call: otherwise the
-// sixteen addresses, invariant across the traversal loop, are hoisted out of it and held in (or
-// spilled from) sixteen registers for the whole kernel.
+// Read pieces FIRST .. FIRST+N-1 of row `row` (undoing the swizzle) into out[0 .. 2N).
+// The rows are 256-byte aligned, so the address of piece p is (row address | swizzle << 4) ^ (p << 4):
+// one XOR per read from a single register.  That register is made opaque on every call: otherwise
+// the sixteen addresses are formed one by one and held in (or spilled from) sixteen registers.
 template <int FIRST, int N>
-RTX_DEV void row_read(const Wave& wv, double* out) {
-    unsigned at = ((unsigned)(size_t)wv.rows + wv.lane * (RTX_ROW_DOUBLES * 8u)) | ((wv.lane & 15u) << 4);
+RTX_DEV void row_read(const Wave& wv, const unsigned row, double* out) {
+    unsigned at = ((unsigned)(size_t)wv.rows + row * (RTX_ROW_DOUBLES * 8u)) | ((row & 15u) << 4);
 #ifndef RTX_ROW_HOIST
     asm volatile("" : "+v"(at));
 #endif
@@ -1860,11 +1871,11 @@ RTX_DEV unsigned long long traverse_steps(const Scene& S, const Wave& wv, Lane& 
                 for (int p = 0; p < 16; p++) { const v2d v = gp[p]; rec[2 * p] = v.x; rec[2 * p + 1] = v.y; }
             }
         } else {
-            coop_fetch(wv, wants ? key : -1, blas);
+            const unsigned row = coop_fetch(wv, wants, key, blas);
             // (every lane reads its row, whether it asked for a record or not: a read under the
             // lanes' own condition makes the compiler keep the other lanes' thirty-two registers
             // alive through it, sixty register moves a step)
-            row_read<0, 16>(wv, rec);
+            row_read<0, 16>(wv, row, rec);
             __builtin_amdgcn_wave_barrier();
         }
         if (COUNT) tl.clk_fetch += (unsigned long long)(clock64() - f0);

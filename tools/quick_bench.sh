@@ -7,7 +7,9 @@ for w in ${@:-dragon_metal grass_desert}; do
 import json,sys
 for l in sys.stdin:
     if l.startswith('{'):
-        j=json.loads(l); r=j['roofline']
+        j=json.loads(l); r=j.get('roofline')
+        if r is None:
+            q=j['sequence']; print('$w', 'ms/frame %.3f' % q['ms_per_frame_per_gpu'], 'Mrays/s %.1f' % j['value'], 'trace ms %.3f' % q['trace_ms_per_frame'], 'kernels ms %.3f' % q['kernel_ms_per_frame']); continue
         print('$w', 'ms/frame %.3f' % j['ms_per_step'], 'Mrays/s %.1f' % j['value'], 'trace ms %.3f' % r['trace_ms_per_frame'], 'kernels ms %.3f' % r['all_kernels_ms_per_frame'], 'parity', j.get('parity',{}).get('vs_oracle'))
 " || exit 1
 done
