@@ -529,7 +529,7 @@ def measure_static(R: Rank, args, name, mode, steps, warmup, with_cpu, pipelined
     # r/N of the way round.  The views differ in cost by up to 40 %, so a rank that kept one view
     # would make the slowest view the measure of every N > 1; this way each GPU does the same work
     # at every N, which is what weak scaling compares.
-    turntable = [orbit_camera(cam0, 360.0 * j / steps) for j in range(steps)] if mode == "frames" else None
+    turntable = [orbit_camera(cam0, 0.0 if args.scene_view else 360.0 * j / steps) for j in range(steps)] if mode == "frames" else None
     phase = (rank * steps) // world
 
     # ---- untimed counting pass: rays and traversal work of this rank's step ----------------
@@ -731,7 +731,8 @@ def measure_static(R: Rank, args, name, mode, steps, warmup, with_cpu, pipelined
             "higher_is_better": True, "scaling": "weak" if mode == "frames" else "strong",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": name, "description": descr, "mode": mode,
-                       "sharding": (f"whole frames of a {steps}-frame turntable around the scene (frame 0 = the scene file's camera): "
+                       "sharding": ("whole frames: every step renders the scene file's own view (--scene-view)" if args.scene_view and mode == "frames" else
+                                    f"whole frames of a {steps}-frame turntable around the scene (frame 0 = the scene file's camera): "
                                     "every rank renders each frame once, rank r starting r/N of the way round; no collective"
                                     if mode == "frames" else
                                     f"interleaved {tw}x{th} tiles of one frame, one gather to rank 0 per frame"),
@@ -908,6 +909,9 @@ def parse_args(argv=None):
     ap.add_argument("--mode", choices=["frames", "tiles"], default="frames")
     ap.add_argument("--tile", default="64x8")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--scene-view", action="store_true",
+                    help="mode frames: every step renders the scene file's own camera instead of a turntable frame "
+                         "(comparisons between builds; the frame of the parity check and of the CPU baseline)")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the sequence and tiled-frame measurements that follow the default workload")
     ap.add_argument("--consistent", action="store_true",

@@ -3,7 +3,7 @@
 cd "$(dirname "$0")/.."
 for w in ${@:-dragon_metal grass_desert}; do
   steps=20; [ $w = grass_desert ] && steps=5
-  timeout -k 10 300 python3 -u bench.py --workload $w --steps $steps --warmup 3 --no-cpu-baseline --no-extras 2>/dev/null | python3 -c "
+  timeout -k 10 300 python3 -u bench.py --workload $w --steps $steps --warmup 3 --no-cpu-baseline --no-extras --scene-view 2>/dev/null | python3 -c "
 import json,sys
 for l in sys.stdin:
     if l.startswith('{'):
