@@ -293,8 +293,8 @@ def is_sequence(name: str) -> bool:
 
 
 def orbit_camera(cam, angle_deg: float):
-    """Rotate the camera about the world y axis through the origin (whole-frame sharding
-    gives every rank its own frame of an orbit around the same scene)."""
+    """Rotate the camera about the world y axis through the origin (the frames of the
+    turntable that whole-frame mode times)."""
     from raytracer_amd import Camera
     a = math.radians(angle_deg)
     c, s = math.cos(a), math.sin(a)
@@ -305,6 +305,13 @@ def orbit_camera(cam, angle_deg: float):
         x, y, z = v[0], v[1], v[2]
         getattr(out, name)[:] = [c * x + s * z, y, -s * x + c * z]
     return out
+
+
+def turntable_frame(step: int, rank: int, world: int, frames: int) -> int:
+    """Frame of a `frames`-frame turntable that rank `rank` of `world` renders in step `step`
+    (negative steps are the warm-up): every rank goes once round in `frames` steps, rank r starting
+    r/N of the way round, so all ranks do the same work whatever the frames cost."""
+    return (step + (rank * frames) // world) % frames
 
 
 def reduced_scene_file(scene_json: str, f: int) -> str:
@@ -507,7 +514,8 @@ def pmc_summary(workload):
 
 
 def measure_static(R: Rank, args, name, mode, steps, warmup, with_cpu, pipelined=False):
-    """Workloads with one scene file.  mode frames: rank r renders orbit frame r every step.
+    """Workloads with one scene file.  mode frames: every rank renders each frame of a turntable
+    of `steps` frames once, rank r starting r/N of the way round.
     mode tiles: all ranks render interleaved tiles of ONE frame, gathered on rank 0."""
     import numpy as np
     import raytracer_amd as rt
@@ -530,7 +538,6 @@ def measure_static(R: Rank, args, name, mode, steps, warmup, with_cpu, pipelined
     # would make the slowest view the measure of every N > 1; this way each GPU does the same work
     # at every N, which is what weak scaling compares.
     turntable = [orbit_camera(cam0, 0.0 if args.scene_view else 360.0 * j / steps) for j in range(steps)] if mode == "frames" else None
-    phase = (rank * steps) // world
 
     # ---- untimed counting pass: rays and traversal work of this rank's step ----------------
     R.note("device counting pass")
@@ -589,7 +596,7 @@ def measure_static(R: Rank, args, name, mode, steps, warmup, with_cpu, pipelined
         ds.set_consistent(True)
     if mode == "frames":
         def step(i):
-            return ds.render(turntable[(i + phase) % steps], out=frame)[2]
+            return ds.render(turntable[turntable_frame(i, rank, world, steps)], out=frame)[2]
     else:
         gatherer = D.TileGatherer(cam.width, cam.height, tw, th, rank, world, device=R.red_dev,
                                   unpack=rt.unpack_tiles, frame=frame)
@@ -619,7 +626,7 @@ def measure_static(R: Rank, args, name, mode, steps, warmup, with_cpu, pipelined
         def burst(d, f, k):
             # (each pipeline renders the whole turntable once, the pipelines a k-th of the way apart)
             for i in range(steps):
-                d.render(turntable[(i + phase + (k * steps) // k_fl) % steps], out=f)
+                d.render(turntable[turntable_frame(i + (k * steps) // k_fl, rank, world, steps)], out=f)
         R.barrier()
         t0 = time.perf_counter()
         threads = [threading.Thread(target=burst, args=(d, f, k + 1)) for k, (d, f) in enumerate(extra)]

@@ -52,3 +52,19 @@ def test_torchrun_still_works():
     assert r.returncode == 0, r.stderr[-2000:]
     j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
     assert j["n_gpus"] == 2
+
+
+def test_turntable_gives_every_rank_every_frame_once():
+    """Whole-frame mode: in K steps every rank renders each of the K turntable frames exactly once
+    (equal work per GPU at every N), and the ranks start evenly spread round the table."""
+    import bench
+    for frames in (1, 5, 20, 37):
+        for world in (1, 2, 4, 8):
+            starts = []
+            for rank in range(world):
+                seen = sorted(bench.turntable_frame(i, rank, world, frames) for i in range(frames))
+                assert seen == list(range(frames))
+                starts.append(bench.turntable_frame(0, rank, world, frames))
+                # the warm-up steps (negative) stay on the table
+                assert 0 <= bench.turntable_frame(-3, rank, world, frames) < frames
+            assert starts == sorted(starts) and starts[0] == 0

@@ -1,7 +1,6 @@
 #!/usr/bin/env python3
-"""Dev helper (GPU box): rays and ms per frame of the N orbit views that `bench.py --gpus N`
-deals to its ranks (rank r renders the view at 360*r/N degrees), all on one GPU: how evenly
-the whole-frame sharding loads the ranks.
+"""Dev helper (GPU box): rays and ms per frame of N views around a workload's scene (the frames of
+the turntable that bench.py's whole-frame mode times), all on one GPU: how much the views differ.
 Usage: tools/orbit_cost.py [workload] [N]"""
 import os
 import sys
