@@ -599,7 +599,7 @@ def measure_static(R: Rank, args, name, mode, steps, warmup, with_cpu, pipelined
             return ds.render(turntable[turntable_frame(i, rank, world, steps)], out=frame)[2]
     else:
         gatherer = D.TileGatherer(cam.width, cam.height, tw, th, rank, world, device=R.red_dev,
-                                  unpack=rt.unpack_tiles, frame=frame)
+                                  unpack=rt.unpack_tiles, frame=frame, assemble=rt.assemble_tiles)
         last = {}
 
         def render_tiles(first, stride, out):
@@ -641,6 +641,11 @@ def measure_static(R: Rank, args, name, mode, steps, warmup, with_cpu, pipelined
             d.close()
         piped = {"frames_in_flight_per_gpu": k_fl, "frames": k_fl * steps * world, "wall_s": el2,
                  "ms_per_frame_per_gpu": el2 / (k_fl * steps) * 1e3}
+    # mode tiles: the assembled frame against the same frame rendered whole on rank 0
+    tiles_identical = None
+    if mode == "tiles" and rank == 0:
+        whole = ds.render(cam)[0]
+        tiles_identical = bool(np.array_equal(whole, frame))
     kernel_ms = sum(s["kernel_ms"] for s in stats)
     trace_ms = sum(s["trace_ms"] for s in stats)
     trace_launches = sum(s["trace_launches"] for s in stats)
@@ -743,6 +748,7 @@ def measure_static(R: Rank, args, name, mode, steps, warmup, with_cpu, pipelined
                                     "every rank renders each frame once, rank r starting r/N of the way round; no collective"
                                     if mode == "frames" else
                                     f"interleaved {tw}x{th} tiles of one frame, one gather to rank 0 per frame"),
+                       "assembled_frame_identical_to_whole_frame": tiles_identical,
                        "resolution": [cam.width, cam.height], "rays_per_step": rays_step,
                        "rays_per_pixel": rays_frame / (cam.width * cam.height) if mode == "frames" else None,
                        "rays_scene_view": rays_rank if mode == "frames" else None,
@@ -897,6 +903,7 @@ def run_rank(args) -> int:
             out["tiled_frame"] = {k: tiles[k] for k in ("value", "unit", "ms_per_step", "n_gpus", "steps", "scaling")}
             out["tiled_frame"].update({"workload": "grass_desert", "sharding": tiles["config"]["sharding"],
                                        "resolution": tiles["config"]["resolution"],
+                                       "assembled_frame_identical_to_whole_frame": tiles["config"]["assembled_frame_identical_to_whole_frame"],
                                        "rays_per_frame": tiles["config"]["rays_per_step"],
                                        "trace_ms_per_frame_rank0": tiles["roofline"]["trace_ms_per_frame"],
                                        "l2": tiles["roofline"]["l2"],

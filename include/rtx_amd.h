@@ -229,6 +229,19 @@ int rtx_unpack_tiles(const uint8_t* packed, int32_t width, int32_t height,
                      int32_t tile_w, int32_t tile_h, int32_t tile_first, int32_t tile_stride,
                      uint8_t* frame);
 
+/* The root's side of a frame rendered as interleaved tiles by n_parts ranks (the counterpart of
+ * the join of the reference's row bands, raytracer.cpp:124-130): parts[r] is rank r's packed
+ * buffer -- tiles r, r + n_parts, ... as rtx_render writes them with tile_first = r,
+ * tile_stride = n_parts -- in DEVICE memory on `device` (e.g. where an RCCL gather has put
+ * them; a rank without tiles may pass NULL).  The tiles are scattered into one row-major frame
+ * on the device and the frame is copied to frame_out (host memory, or device memory on `device`
+ * when frame_is_device != 0): one kernel and one copy instead of a copy and a host-side
+ * rtx_unpack_tiles per rank.  The buffers must be complete when the call is made (it does not
+ * wait for other streams).  Blocking; at most 64 parts. */
+int rtx_assemble_tiles(int32_t device, const uint8_t* const* parts, int32_t n_parts,
+                       int32_t width, int32_t height, int32_t tile_w, int32_t tile_h,
+                       uint8_t* frame_out, int32_t frame_is_device);
+
 /* MeshBVH::build (bvh.cpp:80-102, 187-258) on the device: the reference's tree for one mesh --
  * same boxes, topology, split axes, pre-order numbering and leaf face sets -- from a
  * level-synchronous build (segmented reduction + segmented sort per level) instead of the

@@ -18,7 +18,7 @@ import numpy as np
 from . import _abi
 from ._abi import Camera, HitId, Light, SceneDesc, Stats, HIT_DTYPE  # noqa: F401
 
-__all__ = ["HostScene", "DeviceScene", "render_file", "RtxError"]
+__all__ = ["HostScene", "DeviceScene", "render_file", "unpack_tiles", "assemble_tiles", "RtxError"]
 
 
 class RtxError(RuntimeError):
@@ -229,6 +229,20 @@ def unpack_tiles(packed: np.ndarray, width, height, tile_w, tile_h, first, strid
     packed = np.ascontiguousarray(packed, dtype=np.uint8)
     rc = amd_lib().rtx_unpack_tiles(packed.ctypes.data, width, height, tile_w, tile_h, first, stride,
                                     frame.ctypes.data)
+    if rc != 0:
+        raise RtxError(amd_lib().rtx_last_error().decode())
+
+
+def assemble_tiles(device: int, part_ptrs, width, height, tile_w, tile_h, frame: np.ndarray):
+    """Rank 0 of a tiled frame: scatter the packed tile buffers of all ranks, given as DEVICE
+    pointers on `device` (0 / None for a rank without tiles), into `frame` (host uint8
+    [height][width][3]) with one kernel and one copy (rtx_assemble_tiles).  The buffers must be
+    complete: synchronise whatever filled them first."""
+    n = len(part_ptrs)
+    arr = (C.c_void_p * n)(*[C.c_void_p(int(p) if p else 0) for p in part_ptrs])
+    if frame.dtype != np.uint8 or not frame.flags["C_CONTIGUOUS"] or frame.size != height * width * 3:
+        raise RtxError("frame must be a C-contiguous uint8 array of height * width * 3 bytes")
+    rc = amd_lib().rtx_assemble_tiles(device, arr, n, width, height, tile_w, tile_h, frame.ctypes.data, 0)
     if rc != 0:
         raise RtxError(amd_lib().rtx_last_error().decode())
 

@@ -113,7 +113,7 @@ HIT_DTYPE = [("kind", "<i4"), ("container", "<i4"), ("face", "<i4"), ("src", "<i
 # Symbols every library must export (checked by the CPU-side ABI test).
 AMD_SYMBOLS = ["rtx_build_bvh", "rtx_scene_create", "rtx_scene_update_lights", "rtx_render",
                "rtx_render_noalloc", "rtx_noalloc_scratch_bytes",
-               "rtx_render_output_bytes", "rtx_unpack_tiles", "rtx_scene_set_counters", "rtx_scene_set_consistent",
+               "rtx_render_output_bytes", "rtx_unpack_tiles", "rtx_assemble_tiles", "rtx_scene_set_counters", "rtx_scene_set_consistent",
                "rtx_scene_set_queue_limit", "rtx_scene_destroy", "rtx_last_error",
                "rtx_device_count"]
 HOST_SYMBOLS = ["rtx_host_load", "rtx_host_load_next", "rtx_host_attach_bvh", "rtx_host_desc", "rtx_host_camera_count", "rtx_host_camera",
@@ -176,6 +176,9 @@ def load_amd_lib():
     lib.rtx_unpack_tiles.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                      C.c_int32, C.c_int32, C.c_void_p]
     lib.rtx_unpack_tiles.restype = C.c_int
+    lib.rtx_assemble_tiles.argtypes = [C.c_int32, C.POINTER(C.c_void_p), C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                       C.c_void_p, C.c_int32]
+    lib.rtx_assemble_tiles.restype = C.c_int
     lib.rtx_scene_set_counters.argtypes = [C.c_void_p, C.c_int32]
     lib.rtx_scene_set_counters.restype = C.c_int
     lib.rtx_scene_set_consistent.argtypes = [C.c_void_p, C.c_int32]

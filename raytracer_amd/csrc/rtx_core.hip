@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <numeric>
 #include <string>
 #include <vector>
@@ -708,6 +709,61 @@ int rtx_unpack_tiles(const uint8_t* packed, int32_t width, int32_t height, int32
             memcpy(frame + ((size_t)(y0 + y) * width + x0) * 3, src + (size_t)y * tw * 3, (size_t)w * 3);
         }
     }
+    return RTX_OK;
+}
+
+namespace {
+#define RTX_MAX_PARTS 64
+struct TileParts { const uint8_t* p[RTX_MAX_PARTS]; };
+// One thread per pixel slot of every tile: tile t comes from part t % n_parts, where it is the
+// (t / n_parts)-th packed tile.
+__global__ void k_assemble_tiles(const TileParts parts, const int n_parts, const int width, const int height, const int tw,
+                                 const int th, const int tiles_x, const long long n_slots, uint8_t* __restrict__ frame) {
+    const long long id = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= n_slots) return;
+    const int per_tile = tw * th;
+    const int tile = (int)(id / per_tile), within = (int)(id % per_tile);
+    const int x = (tile % tiles_x) * tw + within % tw, y = (tile / tiles_x) * th + within / tw;
+    if (x >= width || y >= height) return;
+    const uint8_t* src = parts.p[tile % n_parts] + ((size_t)(tile / n_parts) * per_tile + within) * 3;
+    uint8_t* dst = frame + ((size_t)y * width + x) * 3;
+    dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2];
+}
+std::mutex g_assemble_mutex;
+DevBuf g_assemble_frame[RTX_MAX_DEVICES];
+}  // namespace
+
+int rtx_assemble_tiles(int32_t device, const uint8_t* const* parts, int32_t n_parts, int32_t width, int32_t height,
+                       int32_t tw, int32_t th, uint8_t* frame_out, int32_t frame_is_device) {
+    if (!parts || !frame_out) return fail(RTX_EINVAL, "null argument");
+    if (n_parts < 1 || n_parts > RTX_MAX_PARTS) return fail(RTX_EINVAL, "between 1 and 64 tile buffers");
+    if (device < 0 || device >= RTX_MAX_DEVICES) return fail(RTX_EINVAL, "bad device");
+    rtx_camera cam{};
+    cam.width = width; cam.height = height;
+    TileGeom g;
+    int rc = tile_geometry(&cam, tw, th, 0, 1, g);
+    if (rc) return rc;
+    TileParts tp{};
+    for (int r = 0; r < n_parts; r++) {
+        // (a part without tiles -- more ranks than tiles -- may be null)
+        if (!parts[r] && r < g.n_tiles) return fail(RTX_EINVAL, "null tile buffer");
+        tp.p[r] = parts[r];
+    }
+    HIP_TRY(hipSetDevice(device));
+    const size_t bytes = (size_t)width * height * 3;
+    const long long n_slots = (long long)g.n_tiles * tw * th;
+    if (n_slots > (long long)0x7FFFFFFF * 256) return fail(RTX_ELIMIT, "frame too large");
+    std::lock_guard<std::mutex> lock(g_assemble_mutex);
+    uint8_t* frame = frame_out;
+    if (!frame_is_device) {
+        HIP_TRY(g_assemble_frame[device].ensure(bytes));
+        frame = (uint8_t*)g_assemble_frame[device].p;
+    }
+    hipLaunchKernelGGL(k_assemble_tiles, dim3((unsigned)((n_slots + 255) / 256)), dim3(256), 0, 0, tp, n_parts, width, height,
+                       tw, th, g.tiles_x, n_slots, frame);
+    HIP_TRY(hipGetLastError());
+    if (!frame_is_device) HIP_TRY(hipMemcpy(frame_out, frame, bytes, hipMemcpyDeviceToHost));
+    else HIP_TRY(hipStreamSynchronize(0));
     return RTX_OK;
 }
 

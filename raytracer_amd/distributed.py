@@ -53,10 +53,13 @@ class TileGatherer:
     device: where the packed buffers live -- "cuda" for RCCL (the render call writes device
     memory and the gather moves it over xGMI), "cpu" for gloo.  unpack: rtx_unpack_tiles or its
     numpy twin.  frame: optional caller-owned uint8 [height][width][3] array for rank 0's result.
+    assemble (device buffers only): rtx_assemble_tiles as `assemble(device_index, pointers, width,
+    height, tile_w, tile_h, frame)` -- the tiles are then scattered on the GPU and the frame comes
+    down in one copy, instead of one copy and one host-side unpack per rank.
     """
 
     def __init__(self, width, height, tile_w, tile_h, rank, world, group=None, device="cpu",
-                 unpack=unpack_tiles_numpy, frame=None):
+                 unpack=unpack_tiles_numpy, frame=None, assemble=None):
         import torch
         self.geom = (width, height, tile_w, tile_h)
         self.rank, self.world, self.group, self.unpack = rank, world, group, unpack
@@ -65,9 +68,10 @@ class TileGatherer:
         self.mine = torch.zeros(pad, dtype=torch.uint8, device=device)
         self.parts = None
         self.stage = None
+        self.assemble = assemble if self.mine.is_cuda else None
         if rank == 0:
             self.parts = [self.mine] if world == 1 else [torch.empty(pad, dtype=torch.uint8, device=device) for _ in range(world)]
-            if self.mine.is_cuda:                       # page-locked landing area for the device buffers
+            if self.mine.is_cuda and self.assemble is None:     # page-locked landing area for the device buffers
                 self.stage = torch.empty((world, pad), dtype=torch.uint8).pin_memory()
             self.frame = frame if frame is not None else np.zeros((height, width, 3), dtype=np.uint8)
 
@@ -83,6 +87,11 @@ class TileGatherer:
             dist.gather(self.mine, self.parts, dst=0, group=self.group)
         if self.rank != 0:
             return None
+        if self.assemble is not None:
+            torch.cuda.synchronize()                    # the gathered buffers are complete
+            self.assemble(self.mine.device.index, [t.data_ptr() if n else 0 for t, n in zip(self.parts, self.sizes)],
+                          width, height, tile_w, tile_h, self.frame)
+            return self.frame
         if self.stage is not None:
             for r, t in enumerate(self.parts):
                 if self.sizes[r]:

@@ -108,6 +108,51 @@ def test_many_tiny_tiles(tmp_path):
     ds.close(); hs.close()
 
 
+_ASSEMBLE_SCRIPT = r"""
+import sys
+import numpy as np
+import torch
+torch.cuda.init()                      # torch's HIP runtime first: the library then shares it (as in bench.py)
+import raytracer_amd as rt
+hs = rt.HostScene(sys.argv[1])
+ds = rt.DeviceScene(hs.desc, 0)
+cam, _ = hs.camera(0)
+full, _, _ = ds.render(cam)
+for tile, world in (((1, 1), 3), ((5, 3), 7), ((64, 64), 2), ((37, 1), 40), ((16, 8), 4)):
+    parts = []
+    for rank in range(world):
+        n = ds.tile_bytes(cam, tile[0], tile[1], rank, world)
+        buf = torch.full((max(n, 1),), 0xAB, dtype=torch.uint8, device="cuda:0")
+        if n:
+            ds.render_tiles(cam, tile[0], tile[1], rank, world, out_ptr=buf.data_ptr(), out_is_device=True)
+        parts.append((buf, n))
+    torch.cuda.synchronize()
+    frame = np.full_like(full, 0xCD)
+    rt.assemble_tiles(0, [b.data_ptr() if n else 0 for b, n in parts], cam.width, cam.height, tile[0], tile[1], frame)
+    assert np.array_equal(frame, full), (tile, world)
+try:
+    rt.assemble_tiles(0, [0], cam.width, cam.height, 8, 8, np.zeros_like(full))       # a rank with tiles but no buffer
+except rt.RtxError:
+    print("ASSEMBLE-OK")
+"""
+
+
+def test_tiles_assembled_on_the_device(tmp_path):
+    """rtx_assemble_tiles: the packed tile buffers of all ranks, in device memory as an RCCL gather
+    leaves them on rank 0, scattered into the frame by one kernel -- the same bytes as the whole
+    frame, with clipped edge tiles and with more ranks than tiles.  In a process of its own:
+    the buffers are torch tensors, and torch must bring up its HIP runtime before the library
+    is loaded for the two to share one (the order bench.py has)."""
+    import os
+    import subprocess
+    import sys
+    path = scenes.scene_tiny(str(tmp_path), res=(37, 29))
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    r = subprocess.run([sys.executable, "-c", _ASSEMBLE_SCRIPT, path], env=env, capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0 and "ASSEMBLE-OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
 def test_queues_regrow_when_a_larger_frame_follows(tmp_path):
     """The ray queues are sized by the first frame; a much larger one overflows them, the
     library grows them and renders the frame again -- with the same result as a fresh scene."""
