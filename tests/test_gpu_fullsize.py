@@ -112,7 +112,8 @@ def test_consistent_mode_at_size(workloads, name, factor):
     assert len(ck.compare_hits(hits, o_hits, allow_src_unknown=False)) == 0, name
     same, mx = ck.image_diff(rgb, o_rgb)
     assert mx <= MAX_DELTA and same >= MIN_SAME, f"{name} (consistent): {same:.5f} identical, max delta {mx}"
-    assert st["instance_path"] == (2 if name == "grass_desert" or name == "marching_dragons" else 0)
+    # (the nearest-first walk is taken from 32 instances on; marching_dragons, with eight, replays them)
+    assert st["instance_path"] == (2 if name == "grass_desert" else 0)
 
 
 @pytest.mark.parametrize("name,tile", [("dragon_metal", (64, 64)), ("grass_desert", (128, 72))])

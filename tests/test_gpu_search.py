@@ -40,6 +40,14 @@ def test_crowded_random_scene(tmp_path, seed):
     assert len(bad) == 0, (seed, bad[:5], hits[bad[:3]], o_hits[bad[:3]])
     same, mx = ck.image_diff(rgb, o_rgb)
     assert mx <= 2 and same >= 0.999, (seed, same, mx)
+    # the consistent mode's nearest-first walk (taken from 32 instances on) against its own checker
+    ds.set_consistent(True)
+    c_rgb, c_hits, _, _ = ck.oracle_render(hs.desc, cam, consistent=True)
+    rgb, hits, st = ds.render(cam, want_hits=True)
+    assert st["instance_path"] == 2
+    assert len(ck.compare_hits(hits, c_hits, allow_src_unknown=False)) == 0, (seed, "consistent")
+    same, mx = ck.image_diff(rgb, c_rgb)
+    assert mx <= 2 and same >= 0.999, (seed, "consistent", same, mx)
     ds.close(); hs.close()
 
 
