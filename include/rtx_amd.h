@@ -277,6 +277,12 @@ int rtx_scene_set_counters(rtx_scene* scene, int32_t enable);
  * (rtx_scene_set_counters) cannot be combined with it: rtx_render returns RTX_EINVAL. */
 int rtx_scene_set_consistent(rtx_scene* scene, int32_t enable);
 
+/* rtx_stats.trace_ms is measured with a pair of events round every ray generation's trace
+ * launches (on by default).  The markers cost a frame about 50 microseconds -- 3-4 % of an
+ * 800x800 frame: callers that do not read trace_ms (the animation pipeline of the command line)
+ * turn them off; trace_ms is then 0.  No counterpart in the reference. */
+int rtx_scene_set_generation_timing(rtx_scene* scene, int32_t enable);
+
 /* Cap, in bytes, of the two ray queues together (default 32 GiB). */
 int rtx_scene_set_queue_limit(rtx_scene* scene, int64_t bytes);
 

@@ -166,6 +166,10 @@ class DeviceScene:
         if self._lib.rtx_scene_set_consistent(self._h, int(enable)) != 0:
             raise RtxError(self._lib.rtx_last_error().decode())
 
+    def set_generation_timing(self, enable: bool):
+        """Events round every generation's trace launches (stats["trace_ms"]; on by default)."""
+        self._lib.rtx_scene_set_generation_timing(self._h, int(enable))
+
     def set_queue_limit(self, nbytes: int):
         self._lib.rtx_scene_set_queue_limit(self._h, int(nbytes))
 

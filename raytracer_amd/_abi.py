@@ -113,7 +113,7 @@ HIT_DTYPE = [("kind", "<i4"), ("container", "<i4"), ("face", "<i4"), ("src", "<i
 # Symbols every library must export (checked by the CPU-side ABI test).
 AMD_SYMBOLS = ["rtx_build_bvh", "rtx_scene_create", "rtx_scene_update_lights", "rtx_render",
                "rtx_render_noalloc", "rtx_noalloc_scratch_bytes",
-               "rtx_render_output_bytes", "rtx_unpack_tiles", "rtx_assemble_tiles", "rtx_scene_set_counters", "rtx_scene_set_consistent",
+               "rtx_render_output_bytes", "rtx_unpack_tiles", "rtx_assemble_tiles", "rtx_scene_set_counters", "rtx_scene_set_consistent", "rtx_scene_set_generation_timing",
                "rtx_scene_set_queue_limit", "rtx_scene_destroy", "rtx_last_error",
                "rtx_device_count"]
 HOST_SYMBOLS = ["rtx_host_load", "rtx_host_load_next", "rtx_host_attach_bvh", "rtx_host_desc", "rtx_host_camera_count", "rtx_host_camera",
@@ -183,6 +183,8 @@ def load_amd_lib():
     lib.rtx_scene_set_counters.restype = C.c_int
     lib.rtx_scene_set_consistent.argtypes = [C.c_void_p, C.c_int32]
     lib.rtx_scene_set_consistent.restype = C.c_int
+    lib.rtx_scene_set_generation_timing.argtypes = [C.c_void_p, C.c_int32]
+    lib.rtx_scene_set_generation_timing.restype = C.c_int
     lib.rtx_scene_set_queue_limit.argtypes = [C.c_void_p, C.c_int64]
     lib.rtx_scene_set_queue_limit.restype = C.c_int
     lib.rtx_scene_destroy.argtypes = [C.c_void_p]

@@ -77,6 +77,7 @@ struct rtx_scene {
     int n_meshes = 0;
     bool counters_on = false;
     bool consistent = false;
+    bool generation_timing = true;  // events round every generation's trace launches (rtx_stats.trace_ms)
     int64_t queue_limit = (int64_t)32 << 30;
     uint32_t queue_capacity = 0;    // rays per queue, grows on overflow and is then kept
     DevBuf materials, lights, xforms, planes, spheres, ftris, meshes, insts, blas, tri_vn;
@@ -673,6 +674,12 @@ int rtx_scene_set_consistent(rtx_scene* sc, int32_t enable) {
     return RTX_OK;
 }
 
+int rtx_scene_set_generation_timing(rtx_scene* sc, int32_t enable) {
+    if (!sc) return fail(RTX_EINVAL, "null scene");
+    sc->generation_timing = enable != 0;
+    return RTX_OK;
+}
+
 int rtx_scene_set_queue_limit(rtx_scene* sc, int64_t bytes) {
     if (!sc || bytes < (int64_t)(1 << 20)) return fail(RTX_EINVAL, "bad queue limit");
     sc->queue_limit = bytes;
@@ -987,7 +994,8 @@ int render_frame(rtx_scene* sc, const rtx_camera* cam, int32_t tw, int32_t th, i
         const bool two_variants = !sc->counters_on && launch.wide_ok && !launch.wide_old;
         HIP_TRY(hipEventRecord(sc->ev0, sc->stream));
         for (int gen = 0; gen < G; gen++) {
-            HIP_TRY(hipEventRecord(gev[2 * gen], sc->stream));
+            const bool timing = sc->generation_timing || gen_timing;
+            if (timing) HIP_TRY(hipEventRecord(gev[2 * gen], sc->stream));
             unsigned blocks = persistent_blocks;
             if (gen == 0) blocks = (unsigned)std::min<int64_t>(persistent_blocks, (n_items0 + 255) / 256);
             rtx_hit_id* aov = (gen == 0 && hit_ids) ? (rtx_hit_id*)M.aov : nullptr;
@@ -997,7 +1005,7 @@ int render_frame(rtx_scene* sc, const rtx_camera* cam, int32_t tw, int32_t th, i
             if (two_variants)
                 hipLaunchKernelGGL(trace_tiny, dim3(blocks), dim3(256), 0, sc->stream, lp, (GenCtrl*)M.ctrl, gen,
                                    (double*)M.accum, aov, (Counters*)nullptr);
-            HIP_TRY(hipEventRecord(gev[2 * gen + 1], sc->stream));
+            if (timing) HIP_TRY(hipEventRecord(gev[2 * gen + 1], sc->stream));
             // the last generation holds shadow rays only: nothing left to shade
             if (gen + 1 < G)
                 hipLaunchKernelGGL(k_shade, dim3(blocks), dim3(256), 0, sc->stream, lp, (GenCtrl*)M.ctrl, gen,
@@ -1022,7 +1030,7 @@ int render_frame(rtx_scene* sc, const rtx_camera* cam, int32_t tw, int32_t th, i
         float ms = 0.f;
         HIP_TRY(hipEventElapsedTime(&ms, sc->ev0, sc->ev1));
         kernel_ms += ms;
-        for (int gen = 0; gen < G; gen++) {
+        for (int gen = 0; gen < G && (sc->generation_timing || gen_timing); gen++) {
             float t = 0.f;
             HIP_TRY(hipEventElapsedTime(&t, gev[2 * gen], gev[2 * gen + 1]));
             trace_ms += t;

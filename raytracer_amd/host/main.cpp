@@ -244,6 +244,7 @@ int main(int argc, char** argv) {
                     return;                                  // no device: nothing else can work either
                 }
                 if (consistent) rtx_scene_set_consistent(d, 1);
+                rtx_scene_set_generation_timing(d, 0);       // (the results file does not report per-generation times)
                 ds.push_back(d);
             }
             upload_ms = std::chrono::duration<double, std::milli>(std::chrono::high_resolution_clock::now() - t0).count();

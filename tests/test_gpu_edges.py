@@ -153,6 +153,22 @@ def test_tiles_assembled_on_the_device(tmp_path):
     assert r.returncode == 0 and "ASSEMBLE-OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
 
 
+def test_generation_timing_off(tmp_path):
+    """rtx_scene_set_generation_timing(0): the same frame, no per-generation trace time."""
+    hs = rt.HostScene(scenes.scene_tiny(str(tmp_path)))
+    ds = rt.DeviceScene(hs.desc, 0)
+    cam, _ = hs.camera(0)
+    a, _, st_a = ds.render(cam)
+    ds.set_generation_timing(False)
+    b, _, st_b = ds.render(cam)
+    ds.set_generation_timing(True)
+    c, _, st_c = ds.render(cam)
+    assert np.array_equal(a, b) and np.array_equal(a, c)
+    assert st_a["trace_ms"] > 0 and st_b["trace_ms"] == 0 and st_c["trace_ms"] > 0
+    assert st_b["kernel_ms"] > 0 and st_b["rays"] == st_a["rays"]
+    ds.close(); hs.close()
+
+
 def test_queues_regrow_when_a_larger_frame_follows(tmp_path):
     """The ray queues are sized by the first frame; a much larger one overflows them, the
     library grows them and renders the frame again -- with the same result as a fresh scene."""
