@@ -811,6 +811,10 @@ def measure_sequence(R: Rank, args, name, steps, warmup, whole, inflight=1):
         hs = rt.HostScene(files[mine[0]][0])
         ds = rt.DeviceScene(hs.desc, R.local_rank)
         cam, _ = hs.camera(0)
+        if inflight > 1:
+            # as the command line's animation pipeline runs: no event pairs round the generations
+            # (rtx_stats.trace_ms stays 0; they cost an 800x800 frame 3-4 %)
+            ds.set_generation_timing(False)
         pipes.append((hs, ds, R.pinned(cam.height * cam.width * 3).reshape(cam.height, cam.width, 3)))
     t_setup = time.time() - t0
     hs, ds, _ = pipes[0]
@@ -860,7 +864,8 @@ def measure_sequence(R: Rank, args, name, steps, warmup, whole, inflight=1):
         out = {"workload": name, "description": descr,
                "sharding": "whole frames: frame f of the sequence on rank f mod N, no collective; geometry parsed, built "
                            "and uploaded once per rank, camera and lights re-read per frame",
-               "frames": int(frames_all), "frames_per_rank": per_rank, "frames_in_flight_per_gpu": len(pipes), "wall_s": elapsed,
+               "frames": int(frames_all), "frames_per_rank": per_rank, "frames_in_flight_per_gpu": len(pipes),
+               "generation_timing": inflight <= 1, "wall_s": elapsed,
                "frames_per_s": frames_all / elapsed, "ms_per_frame_per_gpu": elapsed / per_rank * 1e3,
                "Mrays_per_s": rays_all / elapsed / 1e6, "rays": int(rays_all), "resolution": [cam.width, cam.height],
                "setup_s_per_rank": t_setup, "kernel_ms_per_frame": sum(s["kernel_ms"] for s in stats) / max(len(stats), 1),
@@ -898,7 +903,7 @@ def run_rank(args) -> int:
         tiles = measure_static(R, args, "grass_desert", "tiles", 5, 1, with_cpu=False)
         if R.rank == 0:
             out["sequence"] = seq
-            out["sequence"]["frames_in_flight"] = {k: seq2[k] for k in ("frames_in_flight_per_gpu", "wall_s", "frames_per_s",
+            out["sequence"]["frames_in_flight"] = {k: seq2[k] for k in ("frames_in_flight_per_gpu", "generation_timing", "wall_s", "frames_per_s",
                                                                          "ms_per_frame_per_gpu", "Mrays_per_s")}
             out["tiled_frame"] = {k: tiles[k] for k in ("value", "unit", "ms_per_step", "n_gpus", "steps", "scaling")}
             out["tiled_frame"].update({"workload": "grass_desert", "sharding": tiles["config"]["sharding"],
