@@ -78,6 +78,7 @@ struct rtx_scene {
     bool counters_on = false;
     bool consistent = false;
     bool generation_timing = true;  // events round every generation's trace launches (rtx_stats.trace_ms)
+    int gens_hint = 0;              // generations the next frame launches before it looks whether more are needed (0: all)
     int64_t queue_limit = (int64_t)32 << 30;
     uint32_t queue_capacity = 0;    // rays per queue, grows on overflow and is then kept
     DevBuf materials, lights, xforms, planes, spheres, ftris, meshes, insts, blas, tri_vn;
@@ -992,50 +993,84 @@ int render_frame(rtx_scene* sc, const rtx_camera* cam, int32_t tw, int32_t th, i
                              : (launch.wide_old ? k_trace<false, 1, false> : k_trace<false, 0, false>);
         const TraceKernel trace_tiny = sc->consistent ? k_trace<false, 2, true> : k_trace<false, 2, false>;
         const bool two_variants = !sc->counters_on && launch.wide_ok && !launch.wide_old;
-        HIP_TRY(hipEventRecord(sc->ev0, sc->stream));
-        for (int gen = 0; gen < G; gen++) {
-            const bool timing = sc->generation_timing || gen_timing;
-            if (timing) HIP_TRY(hipEventRecord(gev[2 * gen], sc->stream));
-            unsigned blocks = persistent_blocks;
-            if (gen == 0) blocks = (unsigned)std::min<int64_t>(persistent_blocks, (n_items0 + 255) / 256);
-            rtx_hit_id* aov = (gen == 0 && hit_ids) ? (rtx_hit_id*)M.aov : nullptr;
-            hipLaunchKernelGGL(trace_main, dim3(blocks), dim3(256), 0, sc->stream, lp, (GenCtrl*)M.ctrl, gen,
-                               (double*)M.accum, aov, sc->counters_on ? (Counters*)M.counters + gen : (Counters*)nullptr);
-            // the variant for tiny generations (one of the two returns at once; see k_trace)
-            if (two_variants)
-                hipLaunchKernelGGL(trace_tiny, dim3(blocks), dim3(256), 0, sc->stream, lp, (GenCtrl*)M.ctrl, gen,
-                                   (double*)M.accum, aov, (Counters*)nullptr);
-            if (timing) HIP_TRY(hipEventRecord(gev[2 * gen + 1], sc->stream));
-            // the last generation holds shadow rays only: nothing left to shade
-            if (gen + 1 < G)
-                hipLaunchKernelGGL(k_shade, dim3(blocks), dim3(256), 0, sc->stream, lp, (GenCtrl*)M.ctrl, gen,
-                                   (double*)M.accum);
-        }
-        const unsigned n_values = (unsigned)(n_local_px * 3);
-        hipLaunchKernelGGL(k_resolve, dim3((n_values + 255) / 256), dim3(256), 0, sc->stream,
-                           (const double*)M.accum, (uint8_t*)M.rgb, n_values);
-        HIP_TRY(hipEventRecord(gev[2 * G], sc->stream));
-        HIP_TRY(hipEventRecord(sc->ev1, sc->stream));
-        HIP_TRY(hipGetLastError());
-        // The results follow the kernels down the stream before it is known whether a ray queue
-        // overflowed (that is rare, and the frame is then rendered and copied again): one wait
-        // for kernels, control block and results together.
-        if (rgb_is_device) HIP_TRY(hipMemcpyAsync(rgb_out, M.rgb, (size_t)n_local_px * 3, hipMemcpyDeviceToDevice, sc->stream));
-        else HIP_TRY(hipMemcpyAsync(rgb_out, M.rgb, (size_t)n_local_px * 3, hipMemcpyDeviceToHost, sc->stream));
-        if (hit_ids) HIP_TRY(hipMemcpyAsync(hit_ids, M.aov, (size_t)cam->width * cam->height * sizeof(rtx_hit_id), hipMemcpyDeviceToHost, sc->stream));
-        if (sc->counters_on) HIP_TRY(hipMemcpyAsync(sc->h_counters, M.counters, (size_t)G * sizeof(Counters), hipMemcpyDeviceToHost, sc->stream));
-        HIP_TRY(hipMemcpyAsync(sc->h_ctrl, M.ctrl, ctrl_bytes, hipMemcpyDeviceToHost, sc->stream));
-        HIP_TRY(hipStreamSynchronize(sc->stream));
+        // Generations after a frame's last bounce are empty, and an empty generation still costs its
+        // launches (about 20 microseconds with the gaps round them; four to six of them in a scene of
+        // diffuse surfaces).  The frame therefore launches one generation more than the previous frame
+        // of this scene had rays for, and looks at the next generation's queue when it has the control
+        // blocks back: only if that queue holds rays after all are the remaining generations launched,
+        // and the picture resolved and copied, a second time.  (An empty queue means empty queues ever
+        // after: nothing is skipped that would have done anything.)
+        int g_first = G;
+        if (sc->gens_hint > 0 && !sc->counters_on && !gen_timing && !getenv("RTX_AMD_ALL_GENERATIONS")) g_first = std::min(G, sc->gens_hint);
+        const bool timing = sc->generation_timing || gen_timing;
+        auto launch_generations = [&](const int g0, const int g1) -> int {
+            HIP_TRY(hipEventRecord(sc->ev0, sc->stream));
+            for (int gen = g0; gen < g1; gen++) {
+                if (timing) HIP_TRY(hipEventRecord(gev[2 * gen], sc->stream));
+                unsigned blocks = persistent_blocks;
+                if (gen == 0) blocks = (unsigned)std::min<int64_t>(persistent_blocks, (n_items0 + 255) / 256);
+                rtx_hit_id* aov = (gen == 0 && hit_ids) ? (rtx_hit_id*)M.aov : nullptr;
+                hipLaunchKernelGGL(trace_main, dim3(blocks), dim3(256), 0, sc->stream, lp, (GenCtrl*)M.ctrl, gen,
+                                   (double*)M.accum, aov, sc->counters_on ? (Counters*)M.counters + gen : (Counters*)nullptr);
+                // the variant for tiny generations (one of the two returns at once; see k_trace)
+                if (two_variants)
+                    hipLaunchKernelGGL(trace_tiny, dim3(blocks), dim3(256), 0, sc->stream, lp, (GenCtrl*)M.ctrl, gen,
+                                       (double*)M.accum, aov, (Counters*)nullptr);
+                if (timing) HIP_TRY(hipEventRecord(gev[2 * gen + 1], sc->stream));
+                // the last generation holds shadow rays only: nothing left to shade
+                if (gen + 1 < G)
+                    hipLaunchKernelGGL(k_shade, dim3(blocks), dim3(256), 0, sc->stream, lp, (GenCtrl*)M.ctrl, gen,
+                                       (double*)M.accum);
+            }
+            const unsigned n_values = (unsigned)(n_local_px * 3);
+            hipLaunchKernelGGL(k_resolve, dim3((n_values + 255) / 256), dim3(256), 0, sc->stream,
+                               (const double*)M.accum, (uint8_t*)M.rgb, n_values);
+            HIP_TRY(hipEventRecord(gev[2 * G], sc->stream));
+            HIP_TRY(hipEventRecord(sc->ev1, sc->stream));
+            HIP_TRY(hipGetLastError());
+            // The results follow the kernels down the stream before it is known whether a ray queue
+            // overflowed (that is rare, and the frame is then rendered and copied again): one wait
+            // for kernels, control block and results together.
+            if (rgb_is_device) HIP_TRY(hipMemcpyAsync(rgb_out, M.rgb, (size_t)n_local_px * 3, hipMemcpyDeviceToDevice, sc->stream));
+            else HIP_TRY(hipMemcpyAsync(rgb_out, M.rgb, (size_t)n_local_px * 3, hipMemcpyDeviceToHost, sc->stream));
+            if (hit_ids && g0 == 0) HIP_TRY(hipMemcpyAsync(hit_ids, M.aov, (size_t)cam->width * cam->height * sizeof(rtx_hit_id), hipMemcpyDeviceToHost, sc->stream));
+            if (sc->counters_on) HIP_TRY(hipMemcpyAsync(sc->h_counters, M.counters, (size_t)G * sizeof(Counters), hipMemcpyDeviceToHost, sc->stream));
+            HIP_TRY(hipMemcpyAsync(sc->h_ctrl, M.ctrl, ctrl_bytes, hipMemcpyDeviceToHost, sc->stream));
+            HIP_TRY(hipStreamSynchronize(sc->stream));
+            float ms = 0.f;
+            HIP_TRY(hipEventElapsedTime(&ms, sc->ev0, sc->ev1));
+            kernel_ms += ms;
+            for (int gen = g0; gen < g1 && timing; gen++) {
+                float t = 0.f;
+                HIP_TRY(hipEventElapsedTime(&t, gev[2 * gen], gev[2 * gen + 1]));
+                trace_ms += t;
+            }
+            trace_launches += (uint32_t)(g1 - g0);
+            return RTX_OK;
+        };
+        rc = launch_generations(0, g_first);
+        if (rc) return rc;
         const GenCtrl* ctrl = sc->h_ctrl;
-        float ms = 0.f;
-        HIP_TRY(hipEventElapsedTime(&ms, sc->ev0, sc->ev1));
-        kernel_ms += ms;
-        for (int gen = 0; gen < G && (sc->generation_timing || gen_timing); gen++) {
-            float t = 0.f;
-            HIP_TRY(hipEventElapsedTime(&t, gev[2 * gen], gev[2 * gen + 1]));
-            trace_ms += t;
+        if (g_first < G) {
+            uint64_t pending = 0;
+            bool stopped = false;
+            for (const SubCount& sub : ctrl[g_first].sub) pending += (sub.counts & 0xFFFFFFFFull) + (sub.counts >> 32);
+            for (int k = 0; k <= G; k++) stopped |= ctrl[k].overflow != 0 || ctrl[k].limit != 0;
+            if (pending != 0 && !stopped) {
+                rc = launch_generations(g_first, G);
+                if (rc) return rc;
+            }
         }
-        trace_launches += (uint32_t)G;
+        {
+            // what the next frame of this scene starts with: one generation more than this one had rays for
+            int used = 1;
+            for (int k = 1; k < G; k++) {
+                uint64_t n = 0;
+                for (const SubCount& sub : ctrl[k].sub) n += (sub.counts & 0xFFFFFFFFull) + (sub.counts >> 32);
+                if (n != 0) used = k + 1;
+            }
+            sc->gens_hint = std::min(G, used + 1);
+        }
         if (gen_timing) {
             for (int gen = 0; gen < G; gen++) {
                 float t_trace = 0.f, t_shade = 0.f;

@@ -153,6 +153,35 @@ def test_tiles_assembled_on_the_device(tmp_path):
     assert r.returncode == 0 and "ASSEMBLE-OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
 
 
+def test_generations_launched_follow_the_previous_frame(tmp_path):
+    """A frame launches one ray generation more than the scene's previous frame had rays for and
+    launches the rest only when the next queue turns out to hold rays: a frame that looks at
+    nothing (camera rays only) followed by the full view must give the full view's bytes and
+    hit records, as a fresh scene does and as RTX_AMD_ALL_GENERATIONS=1 (every generation
+    launched) does."""
+    import os
+    hs = rt.HostScene(scenes.scene_tiny(str(tmp_path)))
+    ds = rt.DeviceScene(hs.desc, 0)
+    cam, _ = hs.camera(0)
+    ref, ref_hits, st = ds.render(cam, want_hits=True)
+    assert st["rays"] > cam.width * cam.height          # (the view spawns shadow and secondary rays)
+    away = type(cam).from_buffer_copy(cam)
+    for k in range(3):
+        away.gaze[k] = -cam.gaze[k]
+    _, _, st_away = ds.render(away)
+    again, again_hits, st2 = ds.render(cam, want_hits=True)      # the previous frame needed fewer generations
+    assert np.array_equal(again, ref) and np.array_equal(again_hits, ref_hits) and st2["rays"] == st["rays"]
+    third, _, st3 = ds.render(cam)                               # ... and this one's predecessor all of them
+    assert np.array_equal(third, ref) and st3["rays"] == st["rays"]
+    os.environ["RTX_AMD_ALL_GENERATIONS"] = "1"                  # (read per frame by the library: development switch)
+    try:
+        full, _, st4 = ds.render(cam)
+    finally:
+        os.environ.pop("RTX_AMD_ALL_GENERATIONS", None)
+    assert np.array_equal(full, ref) and st4["rays"] == st["rays"]
+    ds.close(); hs.close()
+
+
 def test_generation_timing_off(tmp_path):
     """rtx_scene_set_generation_timing(0): the same frame, no per-generation trace time."""
     hs = rt.HostScene(scenes.scene_tiny(str(tmp_path)))
