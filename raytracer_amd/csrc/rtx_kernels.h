@@ -1643,13 +1643,17 @@ __device__ __attribute__((noinline)) WideOut wide_multi(const Scene& S, const Wa
         bool leaf_rest = false;
         bool hit = false; double ht = 0.0; int htri = 0;
         int wlo = INT_MAX, whi = -1;
+        // (rays with an axis-parallel component are rare: the general box test only when an entry's job has one)
+        const bool any_par = __ballot(go && (sl.par & RTX_PAR_AXES) != 0) != 0ull;
         if (go && cnt == 0) {
 #pragma unroll
             for (int k = 0; k < 4; k++) {
                 c[k].ref = k & 1 ? __double2hiint(rec[24 + (k >> 1)]) : __double2loint(rec[24 + (k >> 1)]);
                 c[k].cnt = k & 1 ? __double2hiint(rec[26 + (k >> 1)]) : __double2loint(rec[26 + (k >> 1)]);
                 double e;
-                const bool hitb = box_enter(rec + 6 * k, rec + 6 * k + 3, sl, e);
+                bool hitb;
+                if (any_par) hitb = box_enter(rec + 6 * k, rec + 6 * k + 3, sl, e);
+                else hitb = box_enter_nopar(rec + 6 * k, rec + 6 * k + 3, sl, e);
                 c[k].e = e;
                 const bool pass = hitb & (B >= e);
                 c[k].ok = pass & (c[k].cnt >= 0);
@@ -1662,13 +1666,12 @@ __device__ __attribute__((noinline)) WideOut wide_multi(const Scene& S, const Wa
                     wlo = min(wlo, w); whi = max(whi, w);
                 }
             }
+            // (the job's direction signs ride in its `par` word, see make_slab)
             const int axis0 = __double2loint(rec[28]), axisL = __double2hiint(rec[28]), axisR = __double2loint(rec[29]);
-            const double d0 = axis0 == 0 ? rd.x : (axis0 == 1 ? rd.y : rd.z);
-            const double dl = axisL == 0 ? rd.x : (axisL == 1 ? rd.y : rd.z);
-            const double dr = axisR == 0 ? rd.x : (axisR == 1 ? rd.y : rd.z);
-            cand_swap(c[0], c[1], !(dl >= 0.0) && c[1].cnt >= 0);
-            cand_swap(c[2], c[3], !(dr >= 0.0) && c[3].cnt >= 0);
-            const bool right_first = !(d0 >= 0.0);
+            const unsigned far_first = (unsigned)sl.par >> 4;
+            cand_swap(c[0], c[1], ((far_first >> axisL) & 1u) && c[1].cnt >= 0);
+            cand_swap(c[2], c[3], ((far_first >> axisR) & 1u) && c[3].cnt >= 0);
+            const bool right_first = ((far_first >> axis0) & 1u) != 0u;
             cand_swap(c[0], c[2], right_first);
             cand_swap(c[1], c[3], right_first);
         } else if (go && cnt > 0) {
