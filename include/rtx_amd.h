@@ -201,14 +201,17 @@ int rtx_render(rtx_scene* scene, const rtx_camera* camera,
                uint8_t* rgb_out, int32_t rgb_is_device,
                rtx_hit_id* hit_ids, rtx_stats* stats);
 
-/* rtx_render for callers that cannot allocate device memory (code under HIP graph capture,
- * tight serving loops, harnesses that forbid hipMalloc).  It has no counterpart in the
- * reference.  Same arguments and results as rtx_render (no hit_ids), but every byte of device
+/* rtx_render for callers that cannot allocate device memory (tight serving loops, harnesses that
+ * forbid hipMalloc, code that runs while another thread captures a HIP graph in relaxed mode).  It
+ * has no counterpart in the reference.  Same arguments and results as rtx_render (no hit_ids), but
+ * every byte of device
  * memory the frame needs beyond the scene and rgb_out -- ray queues, hit records, traversal
  * stacks, instance bitmaps, accumulators, control blocks -- comes from one fixed array of
  * rtx_noalloc_scratch_bytes() bytes (64 MiB) that the library holds on every GPU it runs on until
  * the process ends; the call makes no hipMalloc / hipFree and its trace grid is 32 blocks, so it
- * is meant for tiles, not for large frames.  What fits: roughly pixels * (lights + 2) <= 150 000
+ * is meant for tiles, not for large frames.  The call itself is blocking (it records events, copies
+ * its control blocks back and waits for its stream), so it cannot be captured into a graph.  What
+ * fits: roughly pixels * (lights + 2) <= 150 000
  * queued rays (e.g. a 192 x 192 tile with two lights); a larger request fails with RTX_ELIMIT
  * and a message that states the bytes needed, a queue overflow at run time (deep dielectric
  * branching) fails with RTX_ENOMEM instead of growing the queues.  Pass page-locked or device
@@ -218,6 +221,35 @@ int rtx_render_noalloc(rtx_scene* scene, const rtx_camera* camera,
                        int32_t tile_w, int32_t tile_h, int32_t tile_first, int32_t tile_stride,
                        uint8_t* rgb_out, int32_t rgb_is_device, rtx_stats* stats);
 int64_t rtx_noalloc_scratch_bytes(void);
+
+/* Several cameras of ONE uploaded scene in flight at once.  The reference renders an animation as one
+ * process per frame file (runner.py:105-141) and the cameras of a file one after the other
+ * (raytracer.cpp:252-264); here a frame context owns everything a render needs besides the scene
+ * -- a stream, ray queues, hit records, traversal stacks, pixel sums, control blocks -- while
+ * geometry, instance hierarchy and object records are shared read-only, and the lights are
+ * versioned (a render keeps the lights that were current when it was submitted).  The last ray
+ * generations of a frame are a few long rays in an otherwise idle GPU; a neighbouring frame's
+ * kernels fill that time.
+ *   rtx_frame_create   a new frame context of `scene` (about pixels x (lights + 2) x 320 bytes of
+ *                      device memory once used, plus 210 MB of traversal stacks)
+ *   rtx_render_async   rtx_render's arguments (same meaning); returns once the work is queued.
+ *                      rgb_out / hit_ids must stay valid until the wait; page-locked or device
+ *                      memory keeps the final copy asynchronous.  One render per frame at a time.
+ *   rtx_frame_wait     waits for the render, redoes it with larger queues if they overflowed
+ *                      (as rtx_render does), fills `stats` (may be NULL).  The bytes are the same
+ *                      as rtx_render's for the same camera.
+ *   rtx_frame_destroy  waits for the frame's stream and frees the context.  Destroy a scene's
+ *                      frames before the scene (rtx_scene_destroy frees the ones left).
+ * A frame is used by one thread at a time; different frames of one scene may be used from
+ * different threads.  The rtx_scene_set_* switches apply to renders submitted after the call.
+ * rtx_render(scene, ...) is rtx_render_async + rtx_frame_wait on a frame the scene owns. */
+typedef struct rtx_frame rtx_frame;
+int rtx_frame_create(rtx_scene* scene, rtx_frame** out);
+int rtx_render_async(rtx_frame* frame, const rtx_camera* camera,
+                     int32_t tile_w, int32_t tile_h, int32_t tile_first, int32_t tile_stride,
+                     uint8_t* rgb_out, int32_t rgb_is_device, rtx_hit_id* hit_ids);
+int rtx_frame_wait(rtx_frame* frame, rtx_stats* stats);
+void rtx_frame_destroy(rtx_frame* frame);
 
 /* Number of bytes rtx_render writes to rgb_out for the given tiling. */
 int64_t rtx_render_output_bytes(const rtx_camera* camera, int32_t tile_w, int32_t tile_h,
@@ -285,6 +317,22 @@ int rtx_scene_set_generation_timing(rtx_scene* scene, int32_t enable);
 
 /* Cap, in bytes, of the two ray queues together (default 32 GiB). */
 int rtx_scene_set_queue_limit(rtx_scene* scene, int64_t bytes);
+
+/* Development switches, for tests and measurements (no counterpart in the reference); every one
+ * leaves pictures and hit records unchanged.  A scene starts with the switches named in the
+ * process environment when the process creates its first scene (RTX_AMD_NO_SEARCH=1 ... for the
+ * tools under tools/); this call replaces them, for renders submitted after it. */
+enum {
+    RTX_DEBUG_NO_SCATTER = 1,        /* generation 0 hands out pixel blocks in image order            */
+    RTX_DEBUG_POISON_QUEUES = 2,     /* ray queues and hit records start every attempt as 0xFF bytes  */
+    RTX_DEBUG_GEN_TIMING = 4,        /* per-generation kernel times and counters on stderr            */
+    RTX_DEBUG_NO_WIDE = 8,           /* no wave-wide traversal of a generation's last jobs            */
+    RTX_DEBUG_NO_SEARCH = 16,        /* instances always replayed in index order (utils.cpp:756-790)  */
+    RTX_DEBUG_NO_WIDE_OLD = 32,      /* wave-wide traversal only in generations of <= 512 rays        */
+    RTX_DEBUG_ALL_GENERATIONS = 64,  /* every ray generation launched, empty or not                   */
+    RTX_DEBUG_ALL = 127
+};
+int rtx_scene_set_debug(rtx_scene* scene, uint32_t flags);
 
 void rtx_scene_destroy(rtx_scene* scene);
 

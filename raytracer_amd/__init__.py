@@ -18,7 +18,7 @@ import numpy as np
 from . import _abi
 from ._abi import Camera, HitId, Light, SceneDesc, Stats, HIT_DTYPE  # noqa: F401
 
-__all__ = ["HostScene", "DeviceScene", "render_file", "unpack_tiles", "assemble_tiles", "RtxError"]
+__all__ = ["HostScene", "DeviceScene", "Frame", "render_file", "unpack_tiles", "assemble_tiles", "RtxError"]
 
 
 class RtxError(RuntimeError):
@@ -173,6 +173,15 @@ class DeviceScene:
     def set_queue_limit(self, nbytes: int):
         self._lib.rtx_scene_set_queue_limit(self._h, int(nbytes))
 
+    def set_debug(self, flags: int):
+        """Development switches (``_abi.DEBUG_*``; rtx_scene_set_debug): same pictures, other paths."""
+        if self._lib.rtx_scene_set_debug(self._h, int(flags)) != 0:
+            raise RtxError(self._lib.rtx_last_error().decode())
+
+    def frame(self) -> "Frame":
+        """A frame context of this scene: renders submitted through different frames run concurrently."""
+        return Frame(self)
+
     def update_lights(self, lights):
         arr = (Light * len(lights))(*lights)
         if self._lib.rtx_scene_update_lights(self._h, arr, len(lights)) != 0:
@@ -219,12 +228,79 @@ class DeviceScene:
 
     def close(self):
         if getattr(self, "_h", None):
+            for fr in list(getattr(self, "_frames", [])):
+                fr.close()
             self._lib.rtx_scene_destroy(self._h)
             self._h = None
 
     def __del__(self):
         try:
             self.close()
+        except Exception:
+            pass
+
+
+class Frame:
+    """One render in flight on a DeviceScene (rtx_frame_create / rtx_render_async / rtx_frame_wait).
+    ``submit`` returns as soon as the work is queued; ``wait`` returns (rgb, hits, stats) like
+    ``DeviceScene.render``.  Several frames of one scene overlap on the GPU."""
+
+    def __init__(self, scene: DeviceScene):
+        self._lib = scene._lib
+        self._scene = scene
+        h = C.c_void_p()
+        if self._lib.rtx_frame_create(scene._h, C.byref(h)) != 0:
+            raise RtxError(f"rtx_frame_create failed: {self._lib.rtx_last_error().decode()}")
+        self._h = h
+        self._out = None
+        if not hasattr(scene, "_frames"):
+            scene._frames = []
+        scene._frames.append(self)
+
+    def submit(self, cam: Camera, want_hits: bool = False, out=None):
+        if out is None:
+            rgb = np.empty((cam.height, cam.width, 3), dtype=np.uint8)
+        else:
+            if out.dtype != np.uint8 or not out.flags["C_CONTIGUOUS"] or out.size != cam.height * cam.width * 3:
+                raise RtxError("out must be a C-contiguous uint8 array of height * width * 3 bytes")
+            rgb = out.reshape(cam.height, cam.width, 3)
+        hits = np.empty(cam.height * cam.width, dtype=HIT_DTYPE) if want_hits else None
+        rc = self._lib.rtx_render_async(self._h, C.byref(cam), cam.width, cam.height, 0, 1, rgb.ctypes.data, 0,
+                                        hits.ctypes.data if want_hits else None)
+        if rc != 0:
+            raise RtxError(f"rtx_render_async failed ({rc}): {self._lib.rtx_last_error().decode()}")
+        self._out = (rgb, hits)
+
+    def submit_tiles(self, cam: Camera, tile_w: int, tile_h: int, first: int, stride: int, out_ptr: int, out_is_device: bool):
+        rc = self._lib.rtx_render_async(self._h, C.byref(cam), tile_w, tile_h, first, stride, C.c_void_p(out_ptr),
+                                        int(out_is_device), None)
+        if rc != 0:
+            raise RtxError(f"rtx_render_async failed ({rc}): {self._lib.rtx_last_error().decode()}")
+        self._out = (None, None)
+
+    def wait(self):
+        st = Stats()
+        rc = self._lib.rtx_frame_wait(self._h, C.byref(st))
+        if rc != 0:
+            self._out = None
+            raise RtxError(f"rtx_frame_wait failed ({rc}): {self._lib.rtx_last_error().decode()}")
+        rgb, hits = self._out
+        self._out = None
+        return rgb, hits, st.as_dict()
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.rtx_frame_destroy(self._h)
+            self._h = None
+            try:
+                self._scene._frames.remove(self)
+            except ValueError:
+                pass
+
+    def __del__(self):
+        try:
+            if getattr(self._scene, "_h", None):
+                self.close()
         except Exception:
             pass
 

@@ -114,8 +114,12 @@ HIT_DTYPE = [("kind", "<i4"), ("container", "<i4"), ("face", "<i4"), ("src", "<i
 AMD_SYMBOLS = ["rtx_build_bvh", "rtx_scene_create", "rtx_scene_update_lights", "rtx_render",
                "rtx_render_noalloc", "rtx_noalloc_scratch_bytes",
                "rtx_render_output_bytes", "rtx_unpack_tiles", "rtx_assemble_tiles", "rtx_scene_set_counters", "rtx_scene_set_consistent", "rtx_scene_set_generation_timing",
-               "rtx_scene_set_queue_limit", "rtx_scene_destroy", "rtx_last_error",
-               "rtx_device_count"]
+               "rtx_scene_set_queue_limit", "rtx_scene_set_debug", "rtx_scene_destroy", "rtx_last_error",
+               "rtx_device_count", "rtx_frame_create", "rtx_render_async", "rtx_frame_wait", "rtx_frame_destroy"]
+
+# rtx_scene_set_debug switches (include/rtx_amd.h)
+DEBUG_NO_SCATTER, DEBUG_POISON_QUEUES, DEBUG_GEN_TIMING, DEBUG_NO_WIDE = 1, 2, 4, 8
+DEBUG_NO_SEARCH, DEBUG_NO_WIDE_OLD, DEBUG_ALL_GENERATIONS = 16, 32, 64
 HOST_SYMBOLS = ["rtx_host_load", "rtx_host_load_next", "rtx_host_attach_bvh", "rtx_host_desc", "rtx_host_camera_count", "rtx_host_camera",
                 "rtx_host_timings", "rtx_host_dump", "rtx_host_free", "rtx_host_write_ppm",
                 "rtx_host_write_png", "rtx_host_last_error"]
@@ -187,6 +191,17 @@ def load_amd_lib():
     lib.rtx_scene_set_generation_timing.restype = C.c_int
     lib.rtx_scene_set_queue_limit.argtypes = [C.c_void_p, C.c_int64]
     lib.rtx_scene_set_queue_limit.restype = C.c_int
+    lib.rtx_scene_set_debug.argtypes = [C.c_void_p, C.c_uint32]
+    lib.rtx_scene_set_debug.restype = C.c_int
+    lib.rtx_frame_create.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
+    lib.rtx_frame_create.restype = C.c_int
+    lib.rtx_render_async.argtypes = [C.c_void_p, C.POINTER(Camera), C.c_int32, C.c_int32, C.c_int32,
+                                     C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]
+    lib.rtx_render_async.restype = C.c_int
+    lib.rtx_frame_wait.argtypes = [C.c_void_p, C.POINTER(Stats)]
+    lib.rtx_frame_wait.restype = C.c_int
+    lib.rtx_frame_destroy.argtypes = [C.c_void_p]
+    lib.rtx_frame_destroy.restype = None
     lib.rtx_scene_destroy.argtypes = [C.c_void_p]
     lib.rtx_scene_destroy.restype = None
     lib.rtx_last_error.argtypes = []

@@ -4,12 +4,14 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <climits>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <mutex>
 #include <numeric>
 #include <string>
@@ -62,28 +64,27 @@ struct HBox {
 
 }  // namespace
 
+// One version of a scene's point lights.  rtx_scene_update_lights publishes a new version; a frame
+// keeps the version it was submitted with until it has been waited for.
+struct LightSet { DevBuf buf; int n = 0; };
+
+struct rtx_frame;
+
 struct rtx_scene {
     int device = 0;
     int cus = 256;                  // compute units of the device (hipDeviceProp_t::multiProcessorCount)
-    hipStream_t stream = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    std::vector<hipEvent_t> gen_events;   // 2 per generation + 1: brackets of the trace launches
-    // page-locked staging, sized at creation: the frame's Launch block on its way to the device,
-    // the control blocks and counters on their way back (no pageable copies, nothing allocated per frame)
-    Launch* h_launch = nullptr;
-    GenCtrl* h_ctrl = nullptr;
-    Counters* h_counters = nullptr;
-    Scene dev{};                    // kernel argument (device pointers inside)
+    Scene dev{};                    // kernel argument (device pointers inside); lights: see `lights`
     int n_meshes = 0;
     bool counters_on = false;
     bool consistent = false;
     bool generation_timing = true;  // events round every generation's trace launches (rtx_stats.trace_ms)
-    int gens_hint = 0;              // generations the next frame launches before it looks whether more are needed (0: all)
+    uint32_t debug = 0;             // RTX_DEBUG_* development switches (rtx_scene_set_debug)
     int64_t queue_limit = (int64_t)32 << 30;
-    uint32_t queue_capacity = 0;    // rays per queue, grows on overflow and is then kept
-    DevBuf materials, lights, xforms, planes, spheres, ftris, meshes, insts, blas, tri_vn;
-    DevBuf accum, rgb, aov, ctrl, counters, queue[2], hitbuf, launch, stacks, inst_bits;
-    size_t inst_bits_cleared = 0;   // bytes of inst_bits known to be all zero
+    DevBuf materials, xforms, planes, spheres, ftris, meshes, insts, blas, tri_vn;
+    // Geometry is shared read-only by every frame of the scene; the lights are versioned.
+    std::mutex lights_mutex;
+    std::shared_ptr<LightSet> lights;                      // current version
+    std::vector<std::shared_ptr<LightSet>> light_pool;     // every version ever made (reused once no frame holds it)
     int record_levels = 0;          // deepest chain of records in any BLAS or the TLAS
     // Entering instances from the walk of the TLAS stacks a BLAS traversal on top of the walk's
     // entries: the most entries that can need (three per record level), and whether every instance
@@ -93,16 +94,11 @@ struct rtx_scene {
     // Exact mode's search hands a ray back to the index-order replay when its argument does not
     // cover the ray (shrunk instances, mostly).  A scene where that happens to more than one ray in
     // ten pays for both; from the next frame on it is rendered by the replay alone.
-    bool search_unprofitable = false;
-    ~rtx_scene() {
-        for (hipEvent_t e : gen_events) (void)hipEventDestroy(e);
-        if (ev0) (void)hipEventDestroy(ev0);
-        if (ev1) (void)hipEventDestroy(ev1);
-        if (stream) (void)hipStreamDestroy(stream);
-        if (h_launch) (void)hipHostFree(h_launch);
-        if (h_ctrl) (void)hipHostFree(h_ctrl);
-        if (h_counters) (void)hipHostFree(h_counters);
-    }
+    std::atomic<bool> search_unprofitable{false};
+    // Frames (rtx_frame_create) of this scene; `own` is the one behind rtx_render / rtx_render_noalloc.
+    std::mutex frames_mutex;
+    std::vector<rtx_frame*> frames;
+    rtx_frame* own = nullptr;
 };
 
 // ---- scratch of the entry point that allocates nothing (rtx_render_noalloc) -------------------
@@ -113,7 +109,24 @@ struct rtx_scene {
 #define RTX_NOALLOC_BLOCKS 32u        // blocks of its trace grid (each lane has a traversal stack in the scratch)
 #define RTX_MAX_DEVICES 64
 static __device__ __align__(256) unsigned char scratch[RTX_NOALLOC_SCRATCH_BYTES];
-static unsigned char* g_scratch_at[RTX_MAX_DEVICES];   // device address of `scratch` on each GPU
+static unsigned char* g_scratch_at[RTX_MAX_DEVICES];   // device address of `scratch` on each GPU (under g_scratch_mutex)
+static std::mutex g_scratch_mutex;
+
+// Device address of this GPU's copy of the scratch array; `device` must be the current device.
+// Looked up once per device (rtx_scene_create does it; the no-allocation entry point finds it there).
+static hipError_t scratch_address(int device, unsigned char** out) {
+    *out = nullptr;
+    if (device < 0 || device >= RTX_MAX_DEVICES) return hipErrorInvalidDevice;
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (!g_scratch_at[device]) {
+        unsigned char* at = nullptr;
+        const hipError_t e = hipGetSymbolAddress((void**)&at, HIP_SYMBOL(scratch));
+        if (e != hipSuccess) return e;
+        g_scratch_at[device] = at;
+    }
+    *out = g_scratch_at[device];
+    return hipSuccess;
+}
 
 namespace {
 
@@ -535,7 +548,13 @@ int build_scene(rtx_scene& sc, const rtx_scene_desc& d) {
         fill_obj(objs[(size_t)d.n_meshes + (size_t)i], insts[(size_t)i].base_mesh, insts[(size_t)i].xform, insts[(size_t)i].material);
 
     HIP_TRY(sc.materials.upload(mats));   S.materials = (const Material*)sc.materials.p;
-    HIP_TRY(sc.lights.upload(lights));    S.lights = (const Light*)sc.lights.p;
+    {
+        auto ls = std::make_shared<LightSet>();
+        HIP_TRY(ls->buf.upload(lights));
+        ls->n = d.n_lights;
+        sc.lights = ls; sc.light_pool.push_back(ls);
+        S.lights = (const Light*)ls->buf.p;
+    }
     HIP_TRY(sc.xforms.upload(xfs));       S.xforms = (const Xform*)sc.xforms.p;
     HIP_TRY(sc.planes.upload(planes));    S.planes = (const Plane*)sc.planes.p;
     HIP_TRY(sc.spheres.upload(spheres));  S.spheres = (const Sphere*)sc.spheres.p;
@@ -612,88 +631,6 @@ int rtx_device_count(void) {
     return n;
 }
 
-int rtx_scene_create(const rtx_scene_desc* desc, int device, rtx_scene** out) {
-    if (!desc || !out) return fail(RTX_EINVAL, "null argument");
-    int n = 0;
-    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return fail(RTX_ENODEVICE, "no HIP device available");
-    if (device < 0 || device >= n) return fail(RTX_ENODEVICE, "device index out of range");
-    HIP_TRY(hipSetDevice(device));
-    rtx_scene* sc = new rtx_scene();
-    sc->device = device;
-    int rc = build_scene(*sc, *desc);
-    if (rc == RTX_OK) {
-        // everything a frame needs besides device memory is created here, once
-        const size_t G = (size_t)sc->dev.max_depth + 2;
-        hipError_t e = hipStreamCreateWithFlags(&sc->stream, hipStreamNonBlocking);
-        if (e == hipSuccess) e = hipEventCreate(&sc->ev0);
-        if (e == hipSuccess) e = hipEventCreate(&sc->ev1);
-        for (size_t k = 0; k < 2 * G + 1 && e == hipSuccess; k++) {
-            hipEvent_t ev;
-            e = hipEventCreate(&ev);
-            if (e == hipSuccess) sc->gen_events.push_back(ev);
-        }
-        if (e == hipSuccess) e = hipHostMalloc((void**)&sc->h_launch, sizeof(Launch), hipHostMallocDefault);
-        if (e == hipSuccess) e = hipHostMalloc((void**)&sc->h_ctrl, (G + 1) * sizeof(GenCtrl), hipHostMallocDefault);
-        if (e == hipSuccess) e = hipHostMalloc((void**)&sc->h_counters, G * sizeof(Counters), hipHostMallocDefault);
-        hipDeviceProp_t prop;
-        if (e == hipSuccess && hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
-            sc->cus = prop.multiProcessorCount;
-        // device address of this GPU's copy of the no-allocation scratch array
-        if (e == hipSuccess && device < RTX_MAX_DEVICES && !g_scratch_at[device]) {
-            unsigned char* at = nullptr;
-            e = hipGetSymbolAddress((void**)&at, HIP_SYMBOL(scratch));
-            if (e == hipSuccess) g_scratch_at[device] = at;
-        }
-        if (e != hipSuccess) rc = fail(RTX_EHIP, hipGetErrorString(e));
-    }
-    if (rc != RTX_OK) { delete sc; return rc; }
-    *out = sc;
-    return RTX_OK;
-}
-
-int rtx_scene_update_lights(rtx_scene* sc, const rtx_light* lights, int32_t n_lights) {
-    if (!sc || n_lights < 0 || (n_lights > 0 && !lights)) return fail(RTX_EINVAL, "bad argument");
-    HIP_TRY(hipSetDevice(sc->device));
-    std::vector<Light> l((size_t)n_lights);
-    for (int i = 0; i < n_lights; i++) { memcpy(l[(size_t)i].p, lights[i].position, 24); memcpy(l[(size_t)i].i, lights[i].intensity, 24); }
-    HIP_TRY(hipStreamSynchronize(sc->stream));
-    HIP_TRY(sc->lights.upload(l));
-    sc->dev.lights = (const Light*)sc->lights.p;
-    sc->dev.n_lights = n_lights;
-    return RTX_OK;
-}
-
-int rtx_scene_set_counters(rtx_scene* sc, int32_t enable) {
-    if (!sc) return fail(RTX_EINVAL, "null scene");
-    sc->counters_on = enable != 0;
-    return RTX_OK;
-}
-
-int rtx_scene_set_consistent(rtx_scene* sc, int32_t enable) {
-    if (!sc) return fail(RTX_EINVAL, "null scene");
-    sc->consistent = enable != 0;
-    return RTX_OK;
-}
-
-int rtx_scene_set_generation_timing(rtx_scene* sc, int32_t enable) {
-    if (!sc) return fail(RTX_EINVAL, "null scene");
-    sc->generation_timing = enable != 0;
-    return RTX_OK;
-}
-
-int rtx_scene_set_queue_limit(rtx_scene* sc, int64_t bytes) {
-    if (!sc || bytes < (int64_t)(1 << 20)) return fail(RTX_EINVAL, "bad queue limit");
-    sc->queue_limit = bytes;
-    return RTX_OK;
-}
-
-void rtx_scene_destroy(rtx_scene* sc) {
-    if (!sc) return;
-    (void)hipSetDevice(sc->device);
-    if (sc->stream) (void)hipStreamSynchronize(sc->stream);
-    delete sc;
-}
-
 int64_t rtx_render_output_bytes(const rtx_camera* cam, int32_t tw, int32_t th, int32_t first, int32_t stride) {
     TileGeom g;
     if (tile_geometry(cam, tw, th, first, stride, g)) return -1;
@@ -751,13 +688,28 @@ int rtx_assemble_tiles(int32_t device, const uint8_t* const* parts, int32_t n_pa
     TileGeom g;
     int rc = tile_geometry(&cam, tw, th, 0, 1, g);
     if (rc) return rc;
+    HIP_TRY(hipSetDevice(device));
     TileParts tp{};
     for (int r = 0; r < n_parts; r++) {
         // (a part without tiles -- more ranks than tiles -- may be null)
         if (!parts[r] && r < g.n_tiles) return fail(RTX_EINVAL, "null tile buffer");
+        // Every buffer must be device memory of `device` as this process's HIP runtime knows it: a
+        // pointer the runtime has never seen (host memory, another GPU, memory of a second copy of
+        // the runtime in the process) is refused here instead of being handed to a kernel.
+        if (parts[r]) {
+            hipPointerAttribute_t attr;
+            memset(&attr, 0, sizeof attr);
+            const hipError_t e = hipPointerGetAttributes(&attr, parts[r]);
+            if (e != hipSuccess || attr.type != hipMemoryTypeDevice || attr.device != device) {
+                (void)hipGetLastError();
+                char msg[256];
+                snprintf(msg, sizeof msg, "rtx_assemble_tiles: parts[%d] is not device memory of GPU %d known to this HIP runtime (%s)",
+                         r, (int)device, e != hipSuccess ? hipGetErrorString(e) : attr.type != hipMemoryTypeDevice ? "not device memory" : "another device");
+                return fail(RTX_EINVAL, msg);
+            }
+        }
         tp.p[r] = parts[r];
     }
-    HIP_TRY(hipSetDevice(device));
     const size_t bytes = (size_t)width * height * 3;
     const long long n_slots = (long long)g.n_tiles * tw * th;
     if (n_slots > (long long)0x7FFFFFFF * 256) return fail(RTX_ELIMIT, "frame too large");
@@ -777,10 +729,19 @@ int rtx_assemble_tiles(int32_t device, const uint8_t* const* parts, int32_t n_pa
 
 }  // extern "C"
 
+
+// ---- frames ---------------------------------------------------------------------------------
+//
+// A frame context (rtx_frame) owns everything one render call needs besides the scene itself: a
+// stream, event pairs, page-locked staging, ray queues, hit records, traversal stacks, instance
+// bitmaps, pixel sums and control blocks.  The scene's geometry, TLAS and object records are
+// shared read-only, so several frames of one uploaded scene can be in flight at once: the last
+// generations of a frame are a few long rays in an otherwise idle GPU, and a neighbouring
+// frame's kernels fill that time.  rtx_render is "submit + wait" on the scene's own frame.
 namespace {
 
-// Device memory one frame works in: the library's own growing buffers (rtx_render) or pieces of
-// the fixed scratch array (rtx_render_noalloc).
+// Device memory one frame works in: the frame context's own growing buffers, or pieces of the
+// fixed scratch array (rtx_render_noalloc).
 struct FrameMem {
     void *accum = nullptr, *rgb = nullptr, *ctrl = nullptr, *counters = nullptr, *aov = nullptr, *stacks = nullptr;
     void *launch = nullptr, *hitbuf = nullptr, *queue[2] = {nullptr, nullptr};
@@ -789,29 +750,171 @@ struct FrameMem {
     size_t hit_capacity = 0;
 };
 
-// Synchronise the stream when a render call leaves early: copies into the caller's buffers and
-// into the scene's staging memory may still be in flight.
-struct StreamGuard {
-    hipStream_t s; bool armed = true;
-    ~StreamGuard() { if (armed) (void)hipStreamSynchronize(s); }
+using TraceKernel = void (*)(const Launch*, GenCtrl*, int, double*, rtx_hit_id*, Counters*);
+
+// One submitted render: the arguments, what was derived from them, the scene state it was
+// submitted under, and how far it has got.
+struct Job {
+    rtx_camera cam{};
+    int32_t tw = 0, th = 0, first = 0, stride = 1;
+    uint8_t* rgb_out = nullptr;
+    int32_t rgb_is_device = 0;
+    rtx_hit_id* hit_ids = nullptr;
+    bool noalloc = false;
+    bool stage_rgb = false;         // the picture comes down into the frame's page-locked staging and is copied out at the wait
+    TileGeom g{};
+    Frame F{};
+    int G = 0;
+    int64_t n_items0 = 0, n_local_px = 0, queue_want = 0;
+    unsigned persistent_blocks = 0;
+    uint32_t inst_words = 0;
+    size_t accum_bytes = 0, ctrl_bytes = 0, stack_bytes = 0, bits_bytes = 0;
+    FrameMem M;
+    // the scene as it was when the frame was submitted
+    Scene dev{};
+    std::shared_ptr<LightSet> lights;
+    bool counters_on = false, consistent = false, timing = true;
+    uint32_t debug = 0;
+    // progress
+    uint32_t overflows = 0, trace_launches = 0, instance_path = 0;
+    float kernel_ms = 0.f, trace_ms = 0.f;
+    int g_first = 0;
+    bool search = false, two_variants = false;
+    TraceKernel trace_main = nullptr, trace_tiny = nullptr;
+    std::chrono::high_resolution_clock::time_point wall0;
 };
 
-int render_frame(rtx_scene* sc, const rtx_camera* cam, int32_t tw, int32_t th, int32_t first, int32_t stride,
-                 uint8_t* rgb_out, int32_t rgb_is_device, rtx_hit_id* hit_ids, rtx_stats* stats, const bool noalloc) {
-    if (!sc || !cam || !rgb_out) return fail(RTX_EINVAL, "null argument");
-    TileGeom g;
-    int rc = tile_geometry(cam, tw, th, first, stride, g);
+}  // namespace
+
+struct rtx_frame {
+    rtx_scene* sc = nullptr;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::vector<hipEvent_t> gen_events;   // 2 per generation + 1: brackets of the trace launches
+    // page-locked staging, sized at creation: the frame's Launch block on its way to the device,
+    // the control blocks and counters on their way back (no pageable copies, nothing allocated per frame)
+    Launch* h_launch = nullptr;
+    GenCtrl* h_ctrl = nullptr;
+    Counters* h_counters = nullptr;
+    // ... and the picture's, when the caller's buffer is pageable host memory: a copy into such memory
+    // is staged by the runtime and holds the submitting thread until the frame is done
+    uint8_t* h_stage = nullptr;
+    size_t h_stage_bytes = 0;
+    DevBuf accum, rgb, aov, ctrl, counters, queue[2], hitbuf, launch, stacks, inst_bits;
+    size_t inst_bits_cleared = 0;   // bytes of inst_bits known to be all zero
+    uint32_t queue_capacity = 0;    // rays per queue, grows on overflow and is then kept
+    int gens_hint = 0;              // generations the next render launches before it looks whether more are needed (0: all)
+    bool pending = false;           // a render has been submitted and not yet waited for
+    Job job;
+    ~rtx_frame() {
+        for (hipEvent_t e : gen_events) (void)hipEventDestroy(e);
+        if (ev0) (void)hipEventDestroy(ev0);
+        if (ev1) (void)hipEventDestroy(ev1);
+        if (stream) (void)hipStreamDestroy(stream);
+        if (h_launch) (void)hipHostFree(h_launch);
+        if (h_ctrl) (void)hipHostFree(h_ctrl);
+        if (h_counters) (void)hipHostFree(h_counters);
+        if (h_stage) (void)hipHostFree(h_stage);
+    }
+};
+
+namespace {
+
+// Development switches (rtx_scene_set_debug).  A scene starts with the ones named in the process
+// environment when its first scene is created (RTX_AMD_NO_SCATTER, RTX_AMD_POISON_QUEUES,
+// RTX_AMD_GEN_TIMING, RTX_AMD_NO_WIDE, RTX_AMD_NO_SEARCH, RTX_AMD_NO_WIDE_OLD,
+// RTX_AMD_ALL_GENERATIONS: read once per process); nothing reads the environment per frame.
+uint32_t debug_from_environment() {
+    static const uint32_t flags = [] {
+        uint32_t f = 0;
+        if (getenv("RTX_AMD_NO_SCATTER")) f |= RTX_DEBUG_NO_SCATTER;
+        if (getenv("RTX_AMD_POISON_QUEUES")) f |= RTX_DEBUG_POISON_QUEUES;
+        if (getenv("RTX_AMD_GEN_TIMING")) f |= RTX_DEBUG_GEN_TIMING;
+        if (getenv("RTX_AMD_NO_WIDE")) f |= RTX_DEBUG_NO_WIDE;
+        if (getenv("RTX_AMD_NO_SEARCH")) f |= RTX_DEBUG_NO_SEARCH;
+        if (getenv("RTX_AMD_NO_WIDE_OLD")) f |= RTX_DEBUG_NO_WIDE_OLD;
+        if (getenv("RTX_AMD_ALL_GENERATIONS")) f |= RTX_DEBUG_ALL_GENERATIONS;
+        return f;
+    }();
+    return flags;
+}
+
+int frame_create(rtx_scene* sc, rtx_frame** out) {
+    HIP_TRY(hipSetDevice(sc->device));
+    std::unique_ptr<rtx_frame> fr(new rtx_frame());
+    fr->sc = sc;
+    // everything a render needs besides device memory is created here, once
+    const size_t G = (size_t)sc->dev.max_depth + 2;
+    HIP_TRY(hipStreamCreateWithFlags(&fr->stream, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreate(&fr->ev0));
+    HIP_TRY(hipEventCreate(&fr->ev1));
+    for (size_t k = 0; k < 2 * G + 1; k++) {
+        hipEvent_t ev;
+        HIP_TRY(hipEventCreate(&ev));
+        fr->gen_events.push_back(ev);
+    }
+    HIP_TRY(hipHostMalloc((void**)&fr->h_launch, sizeof(Launch), hipHostMallocDefault));
+    HIP_TRY(hipHostMalloc((void**)&fr->h_ctrl, (G + 1) * sizeof(GenCtrl), hipHostMallocDefault));
+    HIP_TRY(hipHostMalloc((void**)&fr->h_counters, G * sizeof(Counters), hipHostMallocDefault));
+    {
+        std::lock_guard<std::mutex> lock(sc->frames_mutex);
+        sc->frames.push_back(fr.get());
+    }
+    *out = fr.release();
+    return RTX_OK;
+}
+
+void frame_destroy(rtx_frame* fr) {
+    rtx_scene* sc = fr->sc;
+    (void)hipSetDevice(sc->device);
+    if (fr->stream) (void)hipStreamSynchronize(fr->stream);
+    {
+        std::lock_guard<std::mutex> lock(sc->frames_mutex);
+        sc->frames.erase(std::remove(sc->frames.begin(), sc->frames.end(), fr), sc->frames.end());
+        if (sc->own == fr) sc->own = nullptr;
+    }
+    delete fr;
+}
+
+// Synchronise the stream when a call leaves early: copies into the caller's buffers and into the
+// frame's staging memory may still be in flight.
+struct StreamGuard {
+    rtx_frame* fr; bool armed = true;
+    ~StreamGuard() { if (armed) { (void)hipStreamSynchronize(fr->stream); fr->pending = false; fr->job.lights.reset(); } }
+};
+
+// Arguments -> everything that does not change between the attempts of one render; device memory.
+int job_prepare(rtx_frame* fr, const rtx_camera* cam, int32_t tw, int32_t th, int32_t first, int32_t stride,
+                uint8_t* rgb_out, int32_t rgb_is_device, rtx_hit_id* hit_ids, const bool noalloc, bool& nothing_to_do) {
+    rtx_scene* sc = fr->sc;
+    nothing_to_do = false;
+    if (!cam || !rgb_out) return fail(RTX_EINVAL, "null argument");
+    Job& J = fr->job;
+    J = Job();
+    int rc = tile_geometry(cam, tw, th, first, stride, J.g);
     if (rc) return rc;
+    const TileGeom& g = J.g;
     const bool whole = (g.n_tiles == 1 && first == 0);
     if (hit_ids && !whole) return fail(RTX_EINVAL, "hit_ids are only available for whole-frame renders");
     if (sc->counters_on && sc->consistent) return fail(RTX_EINVAL, "work counters are not available in consistent mode");
-    if (stats) memset(stats, 0, sizeof *stats);
-    if (g.n_sel == 0) return RTX_OK;
+    J.cam = *cam; J.tw = tw; J.th = th; J.first = first; J.stride = stride;
+    J.rgb_out = rgb_out; J.rgb_is_device = rgb_is_device; J.hit_ids = hit_ids; J.noalloc = noalloc;
+    J.wall0 = std::chrono::high_resolution_clock::now();
+    if (g.n_sel == 0) { nothing_to_do = true; return RTX_OK; }
     HIP_TRY(hipSetDevice(sc->device));
-    auto wall0 = std::chrono::high_resolution_clock::now();
+    // the scene's state as of now: flags, and the current version of the lights
+    J.counters_on = sc->counters_on; J.consistent = sc->consistent; J.debug = sc->debug;
+    J.timing = sc->generation_timing || (sc->debug & RTX_DEBUG_GEN_TIMING);
+    J.dev = sc->dev;
+    {
+        std::lock_guard<std::mutex> lock(sc->lights_mutex);
+        J.lights = sc->lights;
+    }
+    J.dev.lights = (const Light*)J.lights->buf.p;
+    J.dev.n_lights = J.lights->n;
 
     // camera basis: utils.cpp:135-146, evaluated once per frame instead of once per pixel
-    Frame F{};
+    Frame& F = J.F;
     {
         auto norm = [](const double* a, double* o) {
             double len = std::sqrt(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]);
@@ -833,14 +936,14 @@ int render_frame(rtx_scene* sc, const rtx_camera* cam, int32_t tw, int32_t th, i
         F.tile_w = tw; F.tile_h = th; F.tiles_x = g.tiles_x; F.tile_first = first; F.tile_stride = stride;
     }
     const int64_t blocks_per_tile = (int64_t)((tw + 7) / 8) * ((th + 7) / 8);
-    const int64_t n_items0 = (int64_t)g.n_sel * blocks_per_tile * 64;
-    const int64_t n_local_px = (int64_t)g.n_sel * tw * th;
-    if (n_items0 > (int64_t)0x7FFFFFF0 || n_local_px * 3 > (int64_t)0x7FFFFFF0) return fail(RTX_ELIMIT, "frame too large for one call");
-    F.n_items0 = (int32_t)n_items0;
+    J.n_items0 = (int64_t)g.n_sel * blocks_per_tile * 64;
+    J.n_local_px = (int64_t)g.n_sel * tw * th;
+    if (J.n_items0 > (int64_t)0x7FFFFFF0 || J.n_local_px * 3 > (int64_t)0x7FFFFFF0) return fail(RTX_ELIMIT, "frame too large for one call");
+    F.n_items0 = (int32_t)J.n_items0;
     {
-        const uint64_t nb = (uint64_t)(n_items0 >> RTX_SCATTER0_SHIFT);
+        const uint64_t nb = (uint64_t)(J.n_items0 >> RTX_SCATTER0_SHIFT);
         uint64_t mul = 1;
-        if (nb > 8 && !getenv("RTX_AMD_NO_SCATTER")) {
+        if (nb > 8 && !(J.debug & RTX_DEBUG_NO_SCATTER)) {
             auto gcd = [](uint64_t a, uint64_t b) { while (b) { const uint64_t t = a % b; a = b; b = t; } return a; };
             mul = (uint64_t)((double)nb * 0.6180339887498949) | 1u;
             while (gcd(mul, nb) != 1) mul += 2;
@@ -849,58 +952,75 @@ int render_frame(rtx_scene* sc, const rtx_camera* cam, int32_t tw, int32_t th, i
         F.block_mul = (uint32_t)mul; F.n_blocks = (uint32_t)nb;
     }
 
-    const int G = sc->dev.max_depth + 2;
+    J.G = J.dev.max_depth + 2;
+    const int G = J.G;
     // One grid of resident blocks: RTX_TRACE_WAVES waves per SIMD = that many 256-thread blocks per CU.
-    unsigned persistent_blocks = (unsigned)sc->cus * (unsigned)RTX_TRACE_WAVES;
-    if (noalloc) persistent_blocks = std::min(persistent_blocks, RTX_NOALLOC_BLOCKS);
+    J.persistent_blocks = (unsigned)sc->cus * (unsigned)RTX_TRACE_WAVES;
+    if (noalloc) J.persistent_blocks = std::min(J.persistent_blocks, RTX_NOALLOC_BLOCKS);
     // one bit per instance per lane; every ray leaves its lane's bitmap clear
-    const uint32_t inst_words = rtx_bitmap_words(sc->dev.n_insts) + rtx_summary_words(sc->dev.n_insts);
-    const size_t accum_bytes = (size_t)n_local_px * 3 * sizeof(double);
-    const size_t ctrl_bytes = (size_t)(G + 1) * sizeof(GenCtrl);
-    const size_t stack_bytes = (size_t)persistent_blocks * 256u * RTX_STACK * 16u;
-    const size_t bits_bytes = (size_t)persistent_blocks * 256u * inst_words * sizeof(uint32_t);
-    const int64_t queue_want = std::max<int64_t>(n_local_px * (int64_t)(sc->dev.n_lights + 2), 1 << 12);
+    J.inst_words = rtx_bitmap_words(J.dev.n_insts) + rtx_summary_words(J.dev.n_insts);
+    J.accum_bytes = (size_t)J.n_local_px * 3 * sizeof(double);
+    J.ctrl_bytes = (size_t)(G + 1) * sizeof(GenCtrl);
+    J.stack_bytes = (size_t)J.persistent_blocks * 256u * RTX_STACK * 16u;
+    J.bits_bytes = (size_t)J.persistent_blocks * 256u * J.inst_words * sizeof(uint32_t);
+    J.queue_want = std::max<int64_t>(J.n_local_px * (int64_t)(J.dev.n_lights + 2), 1 << 12);
+    if (fr->gen_events.size() < (size_t)2 * G + 1) return fail(RTX_EHIP, "event pool smaller than the generation count");
 
-    FrameMem M;
+    FrameMem& M = J.M;
     if (!noalloc) {
-        HIP_TRY(sc->accum.ensure(accum_bytes));                     M.accum = sc->accum.p;
-        HIP_TRY(sc->rgb.ensure((size_t)n_local_px * 3));            M.rgb = sc->rgb.p;
-        HIP_TRY(sc->ctrl.ensure(ctrl_bytes));                       M.ctrl = sc->ctrl.p;
-        HIP_TRY(sc->counters.ensure((size_t)G * sizeof(Counters))); M.counters = sc->counters.p;   // one block per generation
-        if (hit_ids) { HIP_TRY(sc->aov.ensure((size_t)cam->width * cam->height * sizeof(rtx_hit_id))); M.aov = sc->aov.p; }
-        HIP_TRY(sc->stacks.ensure(stack_bytes));                    M.stacks = sc->stacks.p;
-        HIP_TRY(sc->launch.ensure(sizeof(Launch)));                 M.launch = sc->launch.p;
-        if (bits_bytes > ((size_t)8 << 30)) return fail(RTX_ELIMIT, "too many instances for the per-lane instance bitmaps");
-        if (bits_bytes > sc->inst_bits.bytes || sc->inst_bits_cleared < bits_bytes) {
-            HIP_TRY(sc->inst_bits.ensure(bits_bytes));
-            HIP_TRY(hipMemsetAsync(sc->inst_bits.p, 0, sc->inst_bits.bytes, sc->stream));    // zeroed once
-            sc->inst_bits_cleared = sc->inst_bits.bytes;
+        HIP_TRY(fr->accum.ensure(J.accum_bytes));                   M.accum = fr->accum.p;
+        HIP_TRY(fr->rgb.ensure((size_t)J.n_local_px * 3));          M.rgb = fr->rgb.p;
+        HIP_TRY(fr->ctrl.ensure(J.ctrl_bytes));                     M.ctrl = fr->ctrl.p;
+        HIP_TRY(fr->counters.ensure((size_t)G * sizeof(Counters))); M.counters = fr->counters.p;   // one block per generation
+        if (hit_ids) { HIP_TRY(fr->aov.ensure((size_t)cam->width * cam->height * sizeof(rtx_hit_id))); M.aov = fr->aov.p; }
+        HIP_TRY(fr->stacks.ensure(J.stack_bytes));                  M.stacks = fr->stacks.p;
+        HIP_TRY(fr->launch.ensure(sizeof(Launch)));                 M.launch = fr->launch.p;
+        if (J.bits_bytes > ((size_t)8 << 30)) return fail(RTX_ELIMIT, "too many instances for the per-lane instance bitmaps");
+        if (J.bits_bytes > fr->inst_bits.bytes || fr->inst_bits_cleared < J.bits_bytes) {
+            HIP_TRY(fr->inst_bits.ensure(J.bits_bytes));
+            HIP_TRY(hipMemsetAsync(fr->inst_bits.p, 0, fr->inst_bits.bytes, fr->stream));    // zeroed once
+            fr->inst_bits_cleared = fr->inst_bits.bytes;
         }
-        M.inst_bits = (unsigned*)sc->inst_bits.p;
-        if (sc->queue_capacity == 0) sc->queue_capacity = (uint32_t)std::min<int64_t>(std::max<int64_t>(queue_want, 1 << 16), 0x7FFFFFF0);
+        M.inst_bits = (unsigned*)fr->inst_bits.p;
+        if (!rgb_is_device) {
+            // page-locked (or otherwise known to the runtime): the final copy is a plain DMA into it
+            hipPointerAttribute_t attr;
+            memset(&attr, 0, sizeof attr);
+            const hipError_t e = hipPointerGetAttributes(&attr, rgb_out);
+            if (e != hipSuccess) (void)hipGetLastError();
+            J.stage_rgb = e != hipSuccess || attr.type == hipMemoryTypeUnregistered;
+            const size_t need = (size_t)J.n_local_px * 3;
+            if (J.stage_rgb && fr->h_stage_bytes < need) {
+                if (fr->h_stage) { (void)hipHostFree(fr->h_stage); fr->h_stage = nullptr; fr->h_stage_bytes = 0; }
+                HIP_TRY(hipHostMalloc((void**)&fr->h_stage, need, hipHostMallocDefault));
+                fr->h_stage_bytes = need;
+            }
+        }
+        if (fr->queue_capacity == 0) fr->queue_capacity = (uint32_t)std::min<int64_t>(std::max<int64_t>(J.queue_want, 1 << 16), 0x7FFFFFF0);
     } else {
         // carve the frame's memory out of this GPU's scratch array; nothing is allocated
         if (hit_ids) return fail(RTX_EINVAL, "the no-allocation entry point returns no hit_ids");
-        unsigned char* const base = sc->device < RTX_MAX_DEVICES ? g_scratch_at[sc->device] : nullptr;
-        if (!base) return fail(RTX_EHIP, "the scratch array's device address is not known for this GPU");
+        unsigned char* base = nullptr;
+        if (scratch_address(sc->device, &base) != hipSuccess || !base)
+            return fail(RTX_EHIP, "the scratch array's device address is not known for this GPU");
         size_t at = 0;
         auto take = [&](size_t n) { unsigned char* p = base + at; at += (n + 255) & ~(size_t)255; return (void*)p; };
         M.launch = take(sizeof(Launch));
-        M.ctrl = take(ctrl_bytes);
+        M.ctrl = take(J.ctrl_bytes);
         M.counters = take((size_t)G * sizeof(Counters));
-        M.accum = take(accum_bytes);
-        M.rgb = take((size_t)n_local_px * 3);
-        M.stacks = take(stack_bytes);
-        M.inst_bits = (unsigned*)take(bits_bytes);
+        M.accum = take(J.accum_bytes);
+        M.rgb = take((size_t)J.n_local_px * 3);
+        M.stacks = take(J.stack_bytes);
+        M.inst_bits = (unsigned*)take(J.bits_bytes);
         // the rest: two ray queues (96 B per ray each) and the hit records (128 B per ray)
-        const int64_t need = std::max<int64_t>(queue_want, n_items0);
+        const int64_t need = std::max<int64_t>(J.queue_want, J.n_items0);
         const int64_t room = (int64_t)RTX_NOALLOC_SCRATCH_BYTES - (int64_t)at;
         const int64_t cap = room > 0 ? (room / (int64_t)(2 * kRayBytes + kHitBytes)) / RTX_NSUB * RTX_NSUB : 0;
         if (cap < need || at > RTX_NOALLOC_SCRATCH_BYTES) {
             char msg[256];
             snprintf(msg, sizeof msg, "rtx_render_noalloc: %lld pixels with %d lights and %d instances need %lld bytes of scratch, "
                      "the fixed array has %u; render fewer tiles per call or use rtx_render",
-                     (long long)n_local_px, sc->dev.n_lights, sc->dev.n_insts,
+                     (long long)J.n_local_px, J.dev.n_lights, J.dev.n_insts,
                      (long long)at + need * (long long)(2 * kRayBytes + kHitBytes), RTX_NOALLOC_SCRATCH_BYTES);
             return fail(RTX_ELIMIT, msg);
         }
@@ -910,206 +1030,291 @@ int render_frame(rtx_scene* sc, const rtx_camera* cam, int32_t tw, int32_t th, i
         M.queue[1] = take((size_t)M.queue_capacity * kRayBytes);
         M.hitbuf = take(M.hit_capacity * kHitBytes);
         // the array keeps the last call's contents (possibly another scene's): clear the candidate bitmaps
-        HIP_TRY(hipMemsetAsync(M.inst_bits, 0, bits_bytes, sc->stream));
+        HIP_TRY(hipMemsetAsync(M.inst_bits, 0, J.bits_bytes, fr->stream));
     }
+    return RTX_OK;
+}
 
-    StreamGuard guard{sc->stream};
-    uint32_t overflows = 0;
-    float kernel_ms = 0.f, trace_ms = 0.f;
-    uint32_t trace_launches = 0, instance_path = 0;
-    const bool poison = getenv("RTX_AMD_POISON_QUEUES") != nullptr;   // test aid: queues and hit records start as 0xFF
+// Launch generations [g0, g1) with their shading, the resolve pass and the copies that bring the
+// results down; nothing is waited for.
+int job_enqueue(rtx_frame* fr, const int g0, const int g1) {
+    Job& J = fr->job;
+    const FrameMem& M = J.M;
+    const int G = J.G;
+    const Launch* lp = (const Launch*)M.launch;
+    std::vector<hipEvent_t>& gev = fr->gen_events;
+    HIP_TRY(hipEventRecord(fr->ev0, fr->stream));
+    for (int gen = g0; gen < g1; gen++) {
+        if (J.timing) HIP_TRY(hipEventRecord(gev[2 * gen], fr->stream));
+        unsigned blocks = J.persistent_blocks;
+        if (gen == 0) blocks = (unsigned)std::min<int64_t>(J.persistent_blocks, (J.n_items0 + 255) / 256);
+        rtx_hit_id* aov = (gen == 0 && J.hit_ids) ? (rtx_hit_id*)M.aov : nullptr;
+        hipLaunchKernelGGL(J.trace_main, dim3(blocks), dim3(256), 0, fr->stream, lp, (GenCtrl*)M.ctrl, gen,
+                           (double*)M.accum, aov, J.counters_on ? (Counters*)M.counters + gen : (Counters*)nullptr);
+        // the variant for tiny generations (one of the two returns at once; see k_trace)
+        if (J.two_variants)
+            hipLaunchKernelGGL(J.trace_tiny, dim3(blocks), dim3(256), 0, fr->stream, lp, (GenCtrl*)M.ctrl, gen,
+                               (double*)M.accum, aov, (Counters*)nullptr);
+        if (J.timing) HIP_TRY(hipEventRecord(gev[2 * gen + 1], fr->stream));
+        // the last generation holds shadow rays only: nothing left to shade
+        if (gen + 1 < G)
+            hipLaunchKernelGGL(k_shade, dim3(blocks), dim3(256), 0, fr->stream, lp, (GenCtrl*)M.ctrl, gen,
+                               (double*)M.accum);
+    }
+    const unsigned n_values = (unsigned)(J.n_local_px * 3);
+    hipLaunchKernelGGL(k_resolve, dim3((n_values + 255) / 256), dim3(256), 0, fr->stream,
+                       (const double*)M.accum, (uint8_t*)M.rgb, n_values);
+    HIP_TRY(hipEventRecord(gev[2 * G], fr->stream));
+    HIP_TRY(hipEventRecord(fr->ev1, fr->stream));
+    HIP_TRY(hipGetLastError());
+    // The results follow the kernels down the stream before it is known whether a ray queue
+    // overflowed (that is rare, and the frame is then rendered and copied again): one wait
+    // for kernels, control block and results together.
+    HIP_TRY(hipMemcpyAsync(J.stage_rgb ? fr->h_stage : J.rgb_out, M.rgb, (size_t)J.n_local_px * 3,
+                           J.rgb_is_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, fr->stream));
+    if (J.hit_ids && g0 == 0)
+        HIP_TRY(hipMemcpyAsync(J.hit_ids, M.aov, (size_t)J.cam.width * J.cam.height * sizeof(rtx_hit_id), hipMemcpyDeviceToHost, fr->stream));
+    if (J.counters_on) HIP_TRY(hipMemcpyAsync(fr->h_counters, M.counters, (size_t)G * sizeof(Counters), hipMemcpyDeviceToHost, fr->stream));
+    HIP_TRY(hipMemcpyAsync(fr->h_ctrl, M.ctrl, J.ctrl_bytes, hipMemcpyDeviceToHost, fr->stream));
+    return RTX_OK;
+}
+
+// Wait for what job_enqueue(g0, g1) put on the stream and add up its times.
+int job_collect(rtx_frame* fr, const int g0, const int g1) {
+    Job& J = fr->job;
+    HIP_TRY(hipStreamSynchronize(fr->stream));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, fr->ev0, fr->ev1));
+    J.kernel_ms += ms;
+    for (int gen = g0; gen < g1 && J.timing; gen++) {
+        float t = 0.f;
+        HIP_TRY(hipEventElapsedTime(&t, fr->gen_events[2 * gen], fr->gen_events[2 * gen + 1]));
+        J.trace_ms += t;
+    }
+    J.trace_launches += (uint32_t)(g1 - g0);
+    return RTX_OK;
+}
+
+// One attempt at the frame with the queues as large as they are now: queues, control blocks and
+// pixel sums set up, the kernel variants chosen, the first generations launched.
+int job_start_attempt(rtx_frame* fr) {
+    rtx_scene* sc = fr->sc;
+    Job& J = fr->job;
+    FrameMem& M = J.M;
+    const int G = J.G;
+    if (!J.noalloc) {
+        if ((int64_t)fr->queue_capacity * (int64_t)kRayBytes * 2 > sc->queue_limit) {
+            uint32_t cap = (uint32_t)(sc->queue_limit / (2 * (int64_t)kRayBytes));
+            if (J.overflows > 0 && cap <= fr->queue_capacity / 2 + 1)
+                return fail(RTX_ENOMEM, "ray queues exceed the configured limit; render fewer tiles per call or raise the limit");
+            fr->queue_capacity = cap;
+        }
+        HIP_TRY(fr->queue[0].ensure((size_t)fr->queue_capacity * kRayBytes));
+        HIP_TRY(fr->queue[1].ensure((size_t)fr->queue_capacity * kRayBytes));
+        M.hit_capacity = std::max<size_t>(fr->queue_capacity, (size_t)J.n_items0);
+        HIP_TRY(fr->hitbuf.ensure(M.hit_capacity * kHitBytes));
+        M.queue[0] = fr->queue[0].p; M.queue[1] = fr->queue[1].p; M.hitbuf = fr->hitbuf.p;
+        M.queue_capacity = fr->queue_capacity;
+    }
+    if (J.debug & RTX_DEBUG_POISON_QUEUES) {      // test aid: queues and hit records start as 0xFF
+        HIP_TRY(hipMemsetAsync(M.queue[0], 0xFF, (size_t)M.queue_capacity * kRayBytes, fr->stream));
+        HIP_TRY(hipMemsetAsync(M.queue[1], 0xFF, (size_t)M.queue_capacity * kRayBytes, fr->stream));
+        HIP_TRY(hipMemsetAsync(M.hitbuf, 0xFF, M.hit_capacity * kHitBytes, fr->stream));
+    }
+    const bool gen_timing = (J.debug & RTX_DEBUG_GEN_TIMING) != 0;     // per-generation kernel times on stderr
+    // page-locked, so the copy below is a plain DMA; the previous render's (or attempt's) copy of the
+    // block finished before that render's final wait returned
+    Launch& launch = *fr->h_launch;
+    launch.S = J.dev; launch.F = J.F;
+    launch.S.limit_flag = &((GenCtrl*)M.ctrl)->limit;
+    launch.q[0] = make_queue(M.queue[0], M.queue_capacity);
+    launch.q[1] = make_queue(M.queue[1], M.queue_capacity);
+    launch.hb = make_hitbuf(M.hitbuf, M.hit_capacity);
+    launch.stacks = M.stacks;
+    launch.inst_bits = M.inst_bits; launch.inst_words = J.inst_words;
+    // wave-wide traversal of a drained generation's last jobs: its visiting-order keys hold 26 record levels
+    launch.wide_ok = (sc->record_levels <= 26 && !(J.debug & RTX_DEBUG_NO_WIDE)) ? 1u : 0u;
+    // Instances entered from the walk of the TLAS, nearest first: always in consistent mode; in the
+    // default mode as a search (rtx_kernels.h, search_service) where instances are many.  The
+    // wave-wide traversal knows one job per ray, so these kernels do without it.
+    // (with few instances of large meshes -- marching_dragons: eight -- the replay with its wave-wide
+    // finishing is the faster of the two in either mode: 4.0 against 4.2 ms in consistent mode)
+    const bool nest = J.consistent && !J.counters_on && J.dev.n_insts >= RTX_SEARCH_MIN_INSTS && sc->affine_insts &&
+                      sc->nest_stack_need <= RTX_STACK;
+    const bool search = !J.consistent && !J.counters_on && J.dev.n_insts >= RTX_SEARCH_MIN_INSTS && sc->affine_insts &&
+                        sc->nest_stack_need <= RTX_SEARCH_STACK && !sc->search_unprofitable.load() && !(J.debug & RTX_DEBUG_NO_SEARCH);
+    if (nest || search) launch.wide_ok = 0u;
+    J.search = search;
+    J.instance_path = nest ? 2u : search ? 1u : 0u;
+    // A service pass lasts as long as its slowest lane.  Replaying instance candidates makes
+    // that long (a chain of dependent loads per candidate), so scenes whose many instances are
+    // replayed gather more lanes per pass and claim rays in larger chunks.
+    const bool replay_heavy = J.dev.n_insts >= 256 && !nest && !search;
+    launch.service_threshold = replay_heavy ? RTX_SERVICE_THRESHOLD_INSTANCED : RTX_SERVICE_THRESHOLD;
+    if (gen_timing) fprintf(stderr, "[rtx] instances %d: nearest-first walk %s (affine %d, stack need %d)\n", J.dev.n_insts,
+                            nest ? "consistent" : search ? "search" : "off", (int)sc->affine_insts, sc->nest_stack_need);
+    // ... and, in scenes that are not dominated by instance replay, of the long-running jobs of
+    // every generation's drained waves (a kernel variant of its own; see k_trace)
+    launch.chunk_max = replay_heavy ? RTX_CHUNK_INSTANCED : RTX_CHUNK; launch.pad_launch = 0;
+    launch.wide_old = (launch.wide_ok && J.dev.n_insts < 256 && !(J.debug & RTX_DEBUG_NO_WIDE_OLD)) ? 1u : 0u;
+    HIP_TRY(hipMemcpyAsync(M.launch, &launch, sizeof launch, hipMemcpyHostToDevice, fr->stream));
+
+    HIP_TRY(hipMemsetAsync(M.ctrl, 0, J.ctrl_bytes, fr->stream));
+    HIP_TRY(hipMemsetAsync(M.accum, 0, J.accum_bytes, fr->stream));
+    if (J.counters_on) HIP_TRY(hipMemsetAsync(M.counters, 0, (size_t)G * sizeof(Counters), fr->stream));
+    // every generation's trace launches (main variant and the one for tiny generations) are
+    // bracketed by events: rtx_stats.trace_ms is the sum of their durations
+    J.trace_main =
+        J.counters_on ? k_trace<true, 0, false>
+        : nest ? k_trace<false, 0, true, 1>
+        : search ? k_trace<false, 0, false, 2>
+        : J.consistent ? (launch.wide_old ? k_trace<false, 1, true> : k_trace<false, 0, true>)
+                       : (launch.wide_old ? k_trace<false, 1, false> : k_trace<false, 0, false>);
+    J.trace_tiny = J.consistent ? k_trace<false, 2, true> : k_trace<false, 2, false>;
+    J.two_variants = !J.counters_on && launch.wide_ok && !launch.wide_old;
+    // Generations after a frame's last bounce are empty, and an empty generation still costs its
+    // launches (about 20 microseconds with the gaps round them; four to six of them in a scene of
+    // diffuse surfaces).  The frame therefore launches one generation more than the previous render
+    // of this frame context had rays for, and looks at the next generation's queue when it has the
+    // control blocks back: only if that queue holds rays after all are the remaining generations
+    // launched, and the picture resolved and copied, a second time.  (An empty queue means empty
+    // queues ever after: nothing is skipped that would have done anything.)
+    J.g_first = G;
+    if (fr->gens_hint > 0 && !J.counters_on && !gen_timing && !(J.debug & RTX_DEBUG_ALL_GENERATIONS)) J.g_first = std::min(G, fr->gens_hint);
+    return job_enqueue(fr, 0, J.g_first);
+}
+
+void print_generation_timing(rtx_frame* fr) {
+    Job& J = fr->job;
+    const GenCtrl* ctrl = fr->h_ctrl;
+    const int G = J.G;
+    std::vector<hipEvent_t>& gev = fr->gen_events;
+    for (int gen = 0; gen < G; gen++) {
+        float t_trace = 0.f, t_shade = 0.f;
+        (void)hipEventElapsedTime(&t_trace, gev[2 * gen], gev[2 * gen + 1]);
+        (void)hipEventElapsedTime(&t_shade, gev[2 * gen + 1], gev[2 * gen + 2]);
+        unsigned long long c = (unsigned long long)J.n_items0;
+        if (gen > 0) { c = 0; for (const SubCount& sub : ctrl[gen].sub) c += sub.counts; }
+        fprintf(stderr, "[rtx] gen %d: radiance %u shadow %u trace %.1f us shade (+resolve) %.1f us\n", gen,
+                (unsigned)c, (unsigned)(c >> 32), t_trace * 1e3, t_shade * 1e3);
+    }
+    fprintf(stderr, "[rtx] rays handed back to the replay by the search: list full %u, k turned down %u, another triangle %u, "
+            "not accepted %u, accepted after k %u\n", ctrl[0].search_back[0], ctrl[0].search_back[1], ctrl[0].search_back[2],
+            ctrl[0].search_back[3], ctrl[0].search_back[4]);
+    if (RTX_WAVE_TALLY)
+        for (int gen = 0; gen < G; gen++) {
+            const unsigned long long sum = *(const unsigned long long*)&ctrl[gen].tally[8], packed = *(const unsigned long long*)&ctrl[gen].tally[10];
+            const unsigned long long mx = (packed >> 38) << 6;
+            const unsigned n = ctrl[gen].tally[12];
+            if (n) fprintf(stderr, "[rtx] gen %d: %u waves, mean lifetime %.1f us, longest %.1f us (at 2.4 GHz; %u %% of it in %u wave-wide jobs, %u %% in traversal steps, %u %% in %u service passes): filled %.0f %%; "
+                           "waves by lifetime in 150 us bins: %u %u %u %u %u %u %u %u+; after the queue ran dry: mean %.1f us, longest %.1f us\n", gen, n,
+                           (double)sum / n / 2400.0, (double)mx / 2400.0, (unsigned)(packed >> 31) & 127u, (unsigned)(packed >> 9) & 255u,
+                           (unsigned)(packed >> 24) & 127u, (unsigned)(packed >> 17) & 127u, (unsigned)packed & 511u, 100.0 * (double)sum / n / (double)mx,
+                           ctrl[gen].tally[0], ctrl[gen].tally[1], ctrl[gen].tally[2], ctrl[gen].tally[3], ctrl[gen].tally[4],
+                           ctrl[gen].tally[5], ctrl[gen].tally[6], ctrl[gen].tally[7],
+                           (double)*(const unsigned long long*)&ctrl[gen].tally[14] / n / 2400.0, (double)ctrl[gen].tally[13] * 256.0 / 2400.0);
+        }
+    if (RTX_SEARCH_TALLY)
+        fprintf(stderr, "[rtx] search: instance jobs ended %u (with a hit %u), instances met by the walk %u, walks ended %u (with a k %u), "
+                "probe jobs ended %u (found %u), probes tried %u\n", ctrl[0].tally[0], ctrl[0].tally[1], ctrl[0].tally[2], ctrl[0].tally[3],
+                ctrl[0].tally[4], ctrl[0].tally[5], ctrl[0].tally[6], ctrl[0].tally[7]);
+}
+
+void print_counter_timing(const Job& J, const Counters* per_gen, const Counters& ctr) {
+    for (int gen = 0; gen < J.G; gen++) {
+        const Counters& c = per_gen[(size_t)gen];
+        fprintf(stderr, "[rtx] gen %d: %llu rays, %llu wave-steps, %llu service passes; longest wave %.1f us "
+                "(at 2.4 GHz): %llu steps, %llu service passes\n", gen, c.rays, c.inner_steps + c.leaf_steps,
+                c.service_passes, (double)c.max_wave_ticks / 2400.0, c.max_wave_steps & 0xFFFFFFFFull, c.max_wave_steps >> 32);
+        fprintf(stderr, "[rtx]        longest ray: %llu steps, %s, local pixel %llu\n", c.longest_ray >> 32,
+                (c.longest_ray & 0x80000000ull) ? "shadow" : "radiance", c.longest_ray & 0x7FFFFFFFull);
+        const double nst = (double)std::max(1ull, c.inner_steps + c.leaf_steps);
+        fprintf(stderr, "[rtx]        ticks per wave-step: %.0f (fetch %.0f, pop %.0f); per service pass: %.0f; "
+                "mean wave lifetime %.1f us (traversing %.1f, servicing %.1f)\n",
+                (double)c.clk_traverse / nst, (double)c.clk_fetch / nst, (double)c.clk_pop / nst,
+                (double)c.clk_service / std::max(1ull, c.service_passes),
+                (double)c.clk_total / std::max(1ull, c.waves) / 2400.0, (double)c.clk_traverse / std::max(1ull, c.waves) / 2400.0,
+                (double)c.clk_service / std::max(1ull, c.waves) / 2400.0);
+        fprintf(stderr, "[rtx]        rays by steps (<16 <32 <64 <128 <256 <512 <1024 more): %llu %llu %llu %llu %llu %llu %llu %llu\n",
+                c.ray_steps_hist[0], c.ray_steps_hist[1], c.ray_steps_hist[2], c.ray_steps_hist[3], c.ray_steps_hist[4],
+                c.ray_steps_hist[5], c.ray_steps_hist[6], c.ray_steps_hist[7]);
+        fprintf(stderr, "[rtx]        of which shadow rays: %llu %llu %llu %llu %llu %llu %llu %llu\n",
+                c.shadow_steps_hist[0], c.shadow_steps_hist[1], c.shadow_steps_hist[2], c.shadow_steps_hist[3],
+                c.shadow_steps_hist[4], c.shadow_steps_hist[5], c.shadow_steps_hist[6], c.shadow_steps_hist[7]);
+    }
+    fprintf(stderr, "[rtx] trace waves %llu: ticks/wave total %.0f traverse %.0f service %.0f; service passes %llu "
+            "(%.0f ticks each), traversal steps %llu (%.0f ticks each; fetch %.0f, pop %.0f)\n", ctr.waves,
+            (double)ctr.clk_total / std::max(1ull, ctr.waves), (double)ctr.clk_traverse / std::max(1ull, ctr.waves),
+            (double)ctr.clk_service / std::max(1ull, ctr.waves), ctr.service_passes,
+            (double)ctr.clk_service / std::max(1ull, ctr.service_passes), ctr.inner_steps + ctr.leaf_steps,
+            (double)ctr.clk_traverse / std::max(1ull, ctr.inner_steps + ctr.leaf_steps),
+            (double)ctr.clk_fetch / std::max(1ull, ctr.inner_steps + ctr.leaf_steps),
+            (double)ctr.clk_pop / std::max(1ull, ctr.inner_steps + ctr.leaf_steps));
+    static const char* names[4] = {"begin", "finalize", "next-job", "complete"};
+    for (int k = 0; k < 4; k++)
+        fprintf(stderr, "[rtx]   service %-9s %10llu lane-calls, %8.0f ticks each\n", names[k], ctr.section[4 + k],
+                (double)ctr.section[k] / std::max(1ull, ctr.section[4 + k]));
+}
+
+int frame_submit(rtx_frame* fr, const rtx_camera* cam, int32_t tw, int32_t th, int32_t first, int32_t stride,
+                 uint8_t* rgb_out, int32_t rgb_is_device, rtx_hit_id* hit_ids, const bool noalloc) {
+    if (!fr) return fail(RTX_EINVAL, "null frame");
+    if (fr->pending) return fail(RTX_EINVAL, "the frame has a render in flight: wait for it first");
+    bool nothing = false;
+    int rc = job_prepare(fr, cam, tw, th, first, stride, rgb_out, rgb_is_device, hit_ids, noalloc, nothing);
+    if (rc) { fr->job.lights.reset(); return rc; }
+    fr->pending = true;
+    if (nothing) { fr->job.G = 0; return RTX_OK; }       // (no tile selected: the wait returns empty statistics)
+    StreamGuard guard{fr};
+    rc = job_start_attempt(fr);
+    if (rc) return rc;
+    guard.armed = false;
+    return RTX_OK;
+}
+
+int frame_wait(rtx_frame* fr, rtx_stats* stats) {
+    if (!fr) return fail(RTX_EINVAL, "null frame");
+    if (!fr->pending) return fail(RTX_EINVAL, "the frame has no render in flight");
+    rtx_scene* sc = fr->sc;
+    Job& J = fr->job;
+    if (stats) memset(stats, 0, sizeof *stats);
+    if (J.G == 0) { fr->pending = false; return RTX_OK; }
+    HIP_TRY(hipSetDevice(sc->device));
+    StreamGuard guard{fr};
+    const int G = J.G;
+    const bool gen_timing = (J.debug & RTX_DEBUG_GEN_TIMING) != 0;
+    const GenCtrl* ctrl = fr->h_ctrl;
+    int rc;
     while (true) {
-        if (!noalloc) {
-            if ((int64_t)sc->queue_capacity * (int64_t)kRayBytes * 2 > sc->queue_limit) {
-                uint32_t cap = (uint32_t)(sc->queue_limit / (2 * (int64_t)kRayBytes));
-                if (overflows > 0 && cap <= sc->queue_capacity / 2 + 1)
-                    return fail(RTX_ENOMEM, "ray queues exceed the configured limit; render fewer tiles per call or raise the limit");
-                sc->queue_capacity = cap;
-            }
-            HIP_TRY(sc->queue[0].ensure((size_t)sc->queue_capacity * kRayBytes));
-            HIP_TRY(sc->queue[1].ensure((size_t)sc->queue_capacity * kRayBytes));
-            M.hit_capacity = std::max<size_t>(sc->queue_capacity, (size_t)n_items0);
-            HIP_TRY(sc->hitbuf.ensure(M.hit_capacity * kHitBytes));
-            M.queue[0] = sc->queue[0].p; M.queue[1] = sc->queue[1].p; M.hitbuf = sc->hitbuf.p;
-            M.queue_capacity = sc->queue_capacity;
-        }
-        if (poison) {
-            HIP_TRY(hipMemsetAsync(M.queue[0], 0xFF, (size_t)M.queue_capacity * kRayBytes, sc->stream));
-            HIP_TRY(hipMemsetAsync(M.queue[1], 0xFF, (size_t)M.queue_capacity * kRayBytes, sc->stream));
-            HIP_TRY(hipMemsetAsync(M.hitbuf, 0xFF, M.hit_capacity * kHitBytes, sc->stream));
-        }
-        // page-locked, so the copy below is a plain DMA; the previous frame's (or attempt's) copy of the
-        // block finished before that frame's final wait returned
-        // RTX_AMD_GEN_TIMING=1 (development aid): per-generation kernel times on stderr
-        static const bool gen_timing = getenv("RTX_AMD_GEN_TIMING") != nullptr;
-        Launch& launch = *sc->h_launch;
-        launch.S = sc->dev; launch.F = F;
-        launch.S.limit_flag = &((GenCtrl*)M.ctrl)->limit;
-        launch.q[0] = make_queue(M.queue[0], M.queue_capacity);
-        launch.q[1] = make_queue(M.queue[1], M.queue_capacity);
-        launch.hb = make_hitbuf(M.hitbuf, M.hit_capacity);
-        launch.stacks = M.stacks;
-        launch.inst_bits = M.inst_bits; launch.inst_words = inst_words;
-        // wave-wide traversal of a drained generation's last jobs: its visiting-order keys hold 26 record levels
-        launch.wide_ok = (sc->record_levels <= 26 && !getenv("RTX_AMD_NO_WIDE")) ? 1u : 0u;
-        // Instances entered from the walk of the TLAS, nearest first: always in consistent mode; in the
-        // default mode as a search (rtx_kernels.h, search_service) where instances are many.  The
-        // wave-wide traversal knows one job per ray, so these kernels do without it.
-        // (with few instances of large meshes -- marching_dragons: eight -- the replay with its wave-wide
-        // finishing is the faster of the two in either mode: 4.0 against 4.2 ms in consistent mode)
-        const bool nest = sc->consistent && !sc->counters_on && sc->dev.n_insts >= RTX_SEARCH_MIN_INSTS && sc->affine_insts &&
-                          sc->nest_stack_need <= RTX_STACK;
-        const bool search = !sc->consistent && !sc->counters_on && sc->dev.n_insts >= RTX_SEARCH_MIN_INSTS && sc->affine_insts &&
-                            sc->nest_stack_need <= RTX_SEARCH_STACK && !sc->search_unprofitable && !getenv("RTX_AMD_NO_SEARCH");
-        if (nest || search) launch.wide_ok = 0u;
-        instance_path = nest ? 2u : search ? 1u : 0u;
-        // A service pass lasts as long as its slowest lane.  Replaying instance candidates makes
-        // that long (a chain of dependent loads per candidate), so scenes whose many instances are
-        // replayed gather more lanes per pass and claim rays in larger chunks.
-        const bool replay_heavy = sc->dev.n_insts >= 256 && !nest && !search;
-        launch.service_threshold = replay_heavy ? RTX_SERVICE_THRESHOLD_INSTANCED : RTX_SERVICE_THRESHOLD;
-        if (gen_timing) fprintf(stderr, "[rtx] instances %d: nearest-first walk %s (affine %d, stack need %d)\n", sc->dev.n_insts,
-                                nest ? "consistent" : search ? "search" : "off", (int)sc->affine_insts, sc->nest_stack_need);
-        // ... and, in scenes that are not dominated by instance replay, of the long-running jobs of
-        // every generation's drained waves (a kernel variant of its own; see k_trace)
-        launch.chunk_max = replay_heavy ? RTX_CHUNK_INSTANCED : RTX_CHUNK; launch.pad_launch = 0;
-        launch.wide_old = (launch.wide_ok && sc->dev.n_insts < 256 && !getenv("RTX_AMD_NO_WIDE_OLD")) ? 1u : 0u;
-        HIP_TRY(hipMemcpyAsync(M.launch, &launch, sizeof launch, hipMemcpyHostToDevice, sc->stream));
-        const Launch* lp = (const Launch*)M.launch;
-
-        HIP_TRY(hipMemsetAsync(M.ctrl, 0, ctrl_bytes, sc->stream));
-        HIP_TRY(hipMemsetAsync(M.accum, 0, accum_bytes, sc->stream));
-        if (sc->counters_on) HIP_TRY(hipMemsetAsync(M.counters, 0, (size_t)G * sizeof(Counters), sc->stream));
-        // every generation's trace launches (main variant and the one for tiny generations) are
-        // bracketed by events: rtx_stats.trace_ms is the sum of their durations
-        if (sc->gen_events.size() < (size_t)2 * G + 1) return fail(RTX_EHIP, "event pool smaller than the generation count");
-        std::vector<hipEvent_t>& gev = sc->gen_events;
-        using TraceKernel = void (*)(const Launch*, GenCtrl*, int, double*, rtx_hit_id*, Counters*);
-        const TraceKernel trace_main =
-            sc->counters_on ? k_trace<true, 0, false>
-            : nest ? k_trace<false, 0, true, 1>
-            : search ? k_trace<false, 0, false, 2>
-            : sc->consistent ? (launch.wide_old ? k_trace<false, 1, true> : k_trace<false, 0, true>)
-                             : (launch.wide_old ? k_trace<false, 1, false> : k_trace<false, 0, false>);
-        const TraceKernel trace_tiny = sc->consistent ? k_trace<false, 2, true> : k_trace<false, 2, false>;
-        const bool two_variants = !sc->counters_on && launch.wide_ok && !launch.wide_old;
-        // Generations after a frame's last bounce are empty, and an empty generation still costs its
-        // launches (about 20 microseconds with the gaps round them; four to six of them in a scene of
-        // diffuse surfaces).  The frame therefore launches one generation more than the previous frame
-        // of this scene had rays for, and looks at the next generation's queue when it has the control
-        // blocks back: only if that queue holds rays after all are the remaining generations launched,
-        // and the picture resolved and copied, a second time.  (An empty queue means empty queues ever
-        // after: nothing is skipped that would have done anything.)
-        int g_first = G;
-        if (sc->gens_hint > 0 && !sc->counters_on && !gen_timing && !getenv("RTX_AMD_ALL_GENERATIONS")) g_first = std::min(G, sc->gens_hint);
-        const bool timing = sc->generation_timing || gen_timing;
-        auto launch_generations = [&](const int g0, const int g1) -> int {
-            HIP_TRY(hipEventRecord(sc->ev0, sc->stream));
-            for (int gen = g0; gen < g1; gen++) {
-                if (timing) HIP_TRY(hipEventRecord(gev[2 * gen], sc->stream));
-                unsigned blocks = persistent_blocks;
-                if (gen == 0) blocks = (unsigned)std::min<int64_t>(persistent_blocks, (n_items0 + 255) / 256);
-                rtx_hit_id* aov = (gen == 0 && hit_ids) ? (rtx_hit_id*)M.aov : nullptr;
-                hipLaunchKernelGGL(trace_main, dim3(blocks), dim3(256), 0, sc->stream, lp, (GenCtrl*)M.ctrl, gen,
-                                   (double*)M.accum, aov, sc->counters_on ? (Counters*)M.counters + gen : (Counters*)nullptr);
-                // the variant for tiny generations (one of the two returns at once; see k_trace)
-                if (two_variants)
-                    hipLaunchKernelGGL(trace_tiny, dim3(blocks), dim3(256), 0, sc->stream, lp, (GenCtrl*)M.ctrl, gen,
-                                       (double*)M.accum, aov, (Counters*)nullptr);
-                if (timing) HIP_TRY(hipEventRecord(gev[2 * gen + 1], sc->stream));
-                // the last generation holds shadow rays only: nothing left to shade
-                if (gen + 1 < G)
-                    hipLaunchKernelGGL(k_shade, dim3(blocks), dim3(256), 0, sc->stream, lp, (GenCtrl*)M.ctrl, gen,
-                                       (double*)M.accum);
-            }
-            const unsigned n_values = (unsigned)(n_local_px * 3);
-            hipLaunchKernelGGL(k_resolve, dim3((n_values + 255) / 256), dim3(256), 0, sc->stream,
-                               (const double*)M.accum, (uint8_t*)M.rgb, n_values);
-            HIP_TRY(hipEventRecord(gev[2 * G], sc->stream));
-            HIP_TRY(hipEventRecord(sc->ev1, sc->stream));
-            HIP_TRY(hipGetLastError());
-            // The results follow the kernels down the stream before it is known whether a ray queue
-            // overflowed (that is rare, and the frame is then rendered and copied again): one wait
-            // for kernels, control block and results together.
-            if (rgb_is_device) HIP_TRY(hipMemcpyAsync(rgb_out, M.rgb, (size_t)n_local_px * 3, hipMemcpyDeviceToDevice, sc->stream));
-            else HIP_TRY(hipMemcpyAsync(rgb_out, M.rgb, (size_t)n_local_px * 3, hipMemcpyDeviceToHost, sc->stream));
-            if (hit_ids && g0 == 0) HIP_TRY(hipMemcpyAsync(hit_ids, M.aov, (size_t)cam->width * cam->height * sizeof(rtx_hit_id), hipMemcpyDeviceToHost, sc->stream));
-            if (sc->counters_on) HIP_TRY(hipMemcpyAsync(sc->h_counters, M.counters, (size_t)G * sizeof(Counters), hipMemcpyDeviceToHost, sc->stream));
-            HIP_TRY(hipMemcpyAsync(sc->h_ctrl, M.ctrl, ctrl_bytes, hipMemcpyDeviceToHost, sc->stream));
-            HIP_TRY(hipStreamSynchronize(sc->stream));
-            float ms = 0.f;
-            HIP_TRY(hipEventElapsedTime(&ms, sc->ev0, sc->ev1));
-            kernel_ms += ms;
-            for (int gen = g0; gen < g1 && timing; gen++) {
-                float t = 0.f;
-                HIP_TRY(hipEventElapsedTime(&t, gev[2 * gen], gev[2 * gen + 1]));
-                trace_ms += t;
-            }
-            trace_launches += (uint32_t)(g1 - g0);
-            return RTX_OK;
-        };
-        rc = launch_generations(0, g_first);
-        if (rc) return rc;
-        const GenCtrl* ctrl = sc->h_ctrl;
-        if (g_first < G) {
+        if ((rc = job_collect(fr, 0, J.g_first))) return rc;
+        if (J.g_first < G) {
             uint64_t pending = 0;
             bool stopped = false;
-            for (const SubCount& sub : ctrl[g_first].sub) pending += (sub.counts & 0xFFFFFFFFull) + (sub.counts >> 32);
+            for (const SubCount& sub : ctrl[J.g_first].sub) pending += (sub.counts & 0xFFFFFFFFull) + (sub.counts >> 32);
             for (int k = 0; k <= G; k++) stopped |= ctrl[k].overflow != 0 || ctrl[k].limit != 0;
             if (pending != 0 && !stopped) {
-                rc = launch_generations(g_first, G);
-                if (rc) return rc;
+                if ((rc = job_enqueue(fr, J.g_first, G))) return rc;
+                if ((rc = job_collect(fr, J.g_first, G))) return rc;
             }
         }
         {
-            // what the next frame of this scene starts with: one generation more than this one had rays for
+            // what the next render of this frame context starts with: one generation more than this one had rays for
             int used = 1;
             for (int k = 1; k < G; k++) {
                 uint64_t n = 0;
                 for (const SubCount& sub : ctrl[k].sub) n += (sub.counts & 0xFFFFFFFFull) + (sub.counts >> 32);
                 if (n != 0) used = k + 1;
             }
-            sc->gens_hint = std::min(G, used + 1);
+            fr->gens_hint = std::min(G, used + 1);
         }
-        if (gen_timing) {
-            for (int gen = 0; gen < G; gen++) {
-                float t_trace = 0.f, t_shade = 0.f;
-                (void)hipEventElapsedTime(&t_trace, gev[2 * gen], gev[2 * gen + 1]);
-                (void)hipEventElapsedTime(&t_shade, gev[2 * gen + 1], gev[2 * gen + 2]);
-                unsigned long long c = (unsigned long long)n_items0;
-                if (gen > 0) { c = 0; for (const SubCount& sub : ctrl[gen].sub) c += sub.counts; }
-                fprintf(stderr, "[rtx] gen %d: radiance %u shadow %u trace %.1f us shade (+resolve) %.1f us\n", gen,
-                        (unsigned)c, (unsigned)(c >> 32), t_trace * 1e3, t_shade * 1e3);
-            }
-        }
-        if (search) {
-            uint64_t back = 0, rays = (uint64_t)n_items0;
+        if (J.search) {
+            uint64_t back = 0, rays = (uint64_t)J.n_items0;
             for (unsigned b : ctrl[0].search_back) back += b;
             for (int k = 1; k <= G; k++)
                 for (const SubCount& sub : ctrl[k].sub) rays += (sub.counts & 0xFFFFFFFFull) + (sub.counts >> 32);
-            if (back * 10 > rays) sc->search_unprofitable = true;
+            if (back * 10 > rays) sc->search_unprofitable.store(true);
         }
-        if (gen_timing)
-            fprintf(stderr, "[rtx] rays handed back to the replay by the search: list full %u, k turned down %u, another triangle %u, "
-                    "not accepted %u, accepted after k %u\n", ctrl[0].search_back[0], ctrl[0].search_back[1], ctrl[0].search_back[2],
-                    ctrl[0].search_back[3], ctrl[0].search_back[4]);
-        if (gen_timing && RTX_WAVE_TALLY)
-            for (int gen = 0; gen < G; gen++) {
-                const unsigned long long sum = *(const unsigned long long*)&ctrl[gen].tally[8], packed = *(const unsigned long long*)&ctrl[gen].tally[10];
-                const unsigned long long mx = (packed >> 38) << 6;
-                const unsigned n = ctrl[gen].tally[12];
-                if (n) fprintf(stderr, "[rtx] gen %d: %u waves, mean lifetime %.1f us, longest %.1f us (at 2.4 GHz; %u %% of it in %u wave-wide jobs, %u %% in traversal steps, %u %% in %u service passes): filled %.0f %%; "
-                               "waves by lifetime in 150 us bins: %u %u %u %u %u %u %u %u+; after the queue ran dry: mean %.1f us, longest %.1f us\n", gen, n,
-                               (double)sum / n / 2400.0, (double)mx / 2400.0, (unsigned)(packed >> 31) & 127u, (unsigned)(packed >> 9) & 255u,
-                               (unsigned)(packed >> 24) & 127u, (unsigned)(packed >> 17) & 127u, (unsigned)packed & 511u, 100.0 * (double)sum / n / (double)mx,
-                               ctrl[gen].tally[0], ctrl[gen].tally[1], ctrl[gen].tally[2], ctrl[gen].tally[3], ctrl[gen].tally[4],
-                               ctrl[gen].tally[5], ctrl[gen].tally[6], ctrl[gen].tally[7],
-                               (double)*(const unsigned long long*)&ctrl[gen].tally[14] / n / 2400.0, (double)ctrl[gen].tally[13] * 256.0 / 2400.0);
-            }
-        if (gen_timing && RTX_SEARCH_TALLY)
-            fprintf(stderr, "[rtx] search: instance jobs ended %u (with a hit %u), instances met by the walk %u, walks ended %u (with a k %u), "
-                    "probe jobs ended %u (found %u), probes tried %u\n", ctrl[0].tally[0], ctrl[0].tally[1], ctrl[0].tally[2], ctrl[0].tally[3],
-                    ctrl[0].tally[4], ctrl[0].tally[5], ctrl[0].tally[6], ctrl[0].tally[7]);
+        if (gen_timing) print_generation_timing(fr);
         bool overflow = false, limit = false;
         uint32_t peak = 0;
         for (int k = 0; k <= G; k++) {
@@ -1121,74 +1326,38 @@ int render_frame(rtx_scene* sc, const rtx_camera* cam, int32_t tw, int32_t th, i
                 peak = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(peak, ((sub.counts & 0xFFFFFFFFull) + (sub.counts >> 32)) * RTX_NSUB), 0x7FFFFFF0ull);
         }
         if (limit) return fail(RTX_ELIMIT, "a traversal stack or frontier overflowed on the device: the picture would be incomplete");
-        if (!overflow) {
-            if (stats) {
-                stats->generations = (uint32_t)G;
-                stats->queue_overflows = overflows;
-            }
-            break;
-        }
-        overflows++;
-        if (noalloc) {
+        if (!overflow) break;
+        J.overflows++;
+        if (J.noalloc) {
             char msg[200];
             snprintf(msg, sizeof msg, "rtx_render_noalloc: the ray queues (%u rays each, fixed scratch) overflowed; "
-                     "render fewer tiles per call or use rtx_render", M.queue_capacity);
+                     "render fewer tiles per call or use rtx_render", J.M.queue_capacity);
             return fail(RTX_ENOMEM, msg);
         }
         // (an overflowed generation stops the frame, so `peak` is a lower bound of what is needed: at least double)
-        int64_t want = std::max<int64_t>((int64_t)peak + (peak >> 3), (int64_t)sc->queue_capacity * 2);
-        sc->queue_capacity = (uint32_t)std::min<int64_t>(want, 0x7FFFFFF0);
-        if (overflows > 8) return fail(RTX_ENOMEM, "ray queues kept overflowing");
+        int64_t want = std::max<int64_t>((int64_t)peak + (peak >> 3), (int64_t)fr->queue_capacity * 2);
+        fr->queue_capacity = (uint32_t)std::min<int64_t>(want, 0x7FFFFFF0);
+        if (J.overflows > 8) return fail(RTX_ENOMEM, "ray queues kept overflowing");
+        if ((rc = job_start_attempt(fr))) return rc;
     }
     guard.armed = false;
+    fr->pending = false;
+    J.lights.reset();
+    if (J.stage_rgb) memcpy(J.rgb_out, fr->h_stage, (size_t)J.n_local_px * 3);
 
-    const Counters* per_gen = sc->h_counters;
+    const Counters* per_gen = fr->h_counters;
     Counters ctr{};
-    if (sc->counters_on) {
+    if (J.counters_on) {
         static_assert(sizeof(Counters) % sizeof(unsigned long long) == 0, "Counters is an array of u64");
         for (int gen = 0; gen < G; gen++)
             for (size_t k = 0; k < sizeof(Counters) / sizeof(unsigned long long); k++)
                 ((unsigned long long*)&ctr)[k] += ((const unsigned long long*)&per_gen[gen])[k];
-        if (getenv("RTX_AMD_GEN_TIMING"))
-            for (int gen = 0; gen < G; gen++) {
-                const Counters& c = per_gen[(size_t)gen];
-                fprintf(stderr, "[rtx] gen %d: %llu rays, %llu wave-steps, %llu service passes; longest wave %.1f us "
-                        "(at 2.4 GHz): %llu steps, %llu service passes\n", gen, c.rays, c.inner_steps + c.leaf_steps,
-                        c.service_passes, (double)c.max_wave_ticks / 2400.0, c.max_wave_steps & 0xFFFFFFFFull, c.max_wave_steps >> 32);
-                fprintf(stderr, "[rtx]        longest ray: %llu steps, %s, local pixel %llu\n", c.longest_ray >> 32,
-                        (c.longest_ray & 0x80000000ull) ? "shadow" : "radiance", c.longest_ray & 0x7FFFFFFFull);
-                const double nst = (double)std::max(1ull, c.inner_steps + c.leaf_steps);
-                fprintf(stderr, "[rtx]        ticks per wave-step: %.0f (fetch %.0f, pop %.0f); per service pass: %.0f; "
-                        "mean wave lifetime %.1f us (traversing %.1f, servicing %.1f)\n",
-                        (double)c.clk_traverse / nst, (double)c.clk_fetch / nst, (double)c.clk_pop / nst,
-                        (double)c.clk_service / std::max(1ull, c.service_passes),
-                        (double)c.clk_total / std::max(1ull, c.waves) / 2400.0, (double)c.clk_traverse / std::max(1ull, c.waves) / 2400.0,
-                        (double)c.clk_service / std::max(1ull, c.waves) / 2400.0);
-                fprintf(stderr, "[rtx]        rays by steps (<16 <32 <64 <128 <256 <512 <1024 more): %llu %llu %llu %llu %llu %llu %llu %llu\n",
-                        c.ray_steps_hist[0], c.ray_steps_hist[1], c.ray_steps_hist[2], c.ray_steps_hist[3], c.ray_steps_hist[4],
-                        c.ray_steps_hist[5], c.ray_steps_hist[6], c.ray_steps_hist[7]);
-                fprintf(stderr, "[rtx]        of which shadow rays: %llu %llu %llu %llu %llu %llu %llu %llu\n",
-                        c.shadow_steps_hist[0], c.shadow_steps_hist[1], c.shadow_steps_hist[2], c.shadow_steps_hist[3],
-                        c.shadow_steps_hist[4], c.shadow_steps_hist[5], c.shadow_steps_hist[6], c.shadow_steps_hist[7]);
-            }
-    }
-    if (sc->counters_on && getenv("RTX_AMD_GEN_TIMING"))
-        fprintf(stderr, "[rtx] trace waves %llu: ticks/wave total %.0f traverse %.0f service %.0f; service passes %llu "
-                "(%.0f ticks each), traversal steps %llu (%.0f ticks each; fetch %.0f, pop %.0f)\n", ctr.waves,
-                (double)ctr.clk_total / std::max(1ull, ctr.waves), (double)ctr.clk_traverse / std::max(1ull, ctr.waves),
-                (double)ctr.clk_service / std::max(1ull, ctr.waves), ctr.service_passes,
-                (double)ctr.clk_service / std::max(1ull, ctr.service_passes), ctr.inner_steps + ctr.leaf_steps,
-                (double)ctr.clk_traverse / std::max(1ull, ctr.inner_steps + ctr.leaf_steps),
-                (double)ctr.clk_fetch / std::max(1ull, ctr.inner_steps + ctr.leaf_steps),
-                (double)ctr.clk_pop / std::max(1ull, ctr.inner_steps + ctr.leaf_steps));
-    if (sc->counters_on && getenv("RTX_AMD_GEN_TIMING")) {
-        static const char* names[4] = {"begin", "finalize", "next-job", "complete"};
-        for (int k = 0; k < 4; k++)
-            fprintf(stderr, "[rtx]   service %-9s %10llu lane-calls, %8.0f ticks each\n", names[k], ctr.section[4 + k],
-                    (double)ctr.section[k] / std::max(1ull, ctr.section[4 + k]));
+        if (gen_timing) print_counter_timing(J, per_gen, ctr);
     }
     if (stats) {
-        if (sc->counters_on) {
+        stats->generations = (uint32_t)G;
+        stats->queue_overflows = J.overflows;
+        if (J.counters_on) {
             stats->rays = ctr.rays; stats->primary_rays = ctr.primary; stats->shadow_rays = ctr.shadow;
             stats->secondary_rays = ctr.secondary;
         } else {
@@ -1196,13 +1365,13 @@ int render_frame(rtx_scene* sc, const rtx_camera* cam, int32_t tw, int32_t th, i
             // tiles, and every later ray passed through a queue whose fill levels came back with
             // the control blocks.
             uint64_t primary = 0, radiance = 0, shadow = 0;
-            for (int k = 0; k < g.n_sel; k++) {
-                const int tile = first + k * stride;
-                const int x0 = (tile % g.tiles_x) * tw, y0 = (tile / g.tiles_x) * th;
-                primary += (uint64_t)std::max(0, std::min(tw, cam->width - x0)) * (uint64_t)std::max(0, std::min(th, cam->height - y0));
+            for (int k = 0; k < J.g.n_sel; k++) {
+                const int tile = J.first + k * J.stride;
+                const int x0 = (tile % J.g.tiles_x) * J.tw, y0 = (tile / J.g.tiles_x) * J.th;
+                primary += (uint64_t)std::max(0, std::min(J.tw, J.cam.width - x0)) * (uint64_t)std::max(0, std::min(J.th, J.cam.height - y0));
             }
             for (int k = 1; k <= G; k++)
-                for (const SubCount& sub : sc->h_ctrl[k].sub) { radiance += sub.counts & 0xFFFFFFFFull; shadow += sub.counts >> 32; }
+                for (const SubCount& sub : ctrl[k].sub) { radiance += sub.counts & 0xFFFFFFFFull; shadow += sub.counts >> 32; }
             stats->primary_rays = primary; stats->secondary_rays = radiance; stats->shadow_rays = shadow;
             stats->rays = primary + radiance + shadow;
         }
@@ -1211,10 +1380,10 @@ int render_frame(rtx_scene* sc, const rtx_camera* cam, int32_t tw, int32_t th, i
         stats->tlas_node_visits = ctr.tlas_visits;
         stats->wave_inner_steps = ctr.inner_steps; stats->wave_inner_lanes = ctr.inner_lanes;
         stats->wave_leaf_steps = ctr.leaf_steps; stats->wave_leaf_lanes = ctr.leaf_lanes;
-        stats->kernel_ms = kernel_ms;
-        stats->trace_ms = trace_ms; stats->trace_launches = trace_launches; stats->instance_path = instance_path;
-        for (int k = 0; k <= G; k++) stats->record_fetches += sc->h_ctrl[k].records;
-        stats->total_ms = std::chrono::duration<double, std::milli>(std::chrono::high_resolution_clock::now() - wall0).count();
+        stats->kernel_ms = J.kernel_ms;
+        stats->trace_ms = J.trace_ms; stats->trace_launches = J.trace_launches; stats->instance_path = J.instance_path;
+        for (int k = 0; k <= G; k++) stats->record_fetches += ctrl[k].records;
+        stats->total_ms = std::chrono::duration<double, std::milli>(std::chrono::high_resolution_clock::now() - J.wall0).count();
     }
     return RTX_OK;
 }
@@ -1223,14 +1392,134 @@ int render_frame(rtx_scene* sc, const rtx_camera* cam, int32_t tw, int32_t th, i
 
 extern "C" {
 
+int rtx_scene_create(const rtx_scene_desc* desc, int device, rtx_scene** out) {
+    if (!desc || !out) return fail(RTX_EINVAL, "null argument");
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return fail(RTX_ENODEVICE, "no HIP device available");
+    if (device < 0 || device >= n) return fail(RTX_ENODEVICE, "device index out of range");
+    HIP_TRY(hipSetDevice(device));
+    rtx_scene* sc = new rtx_scene();
+    sc->device = device;
+    sc->debug = debug_from_environment();
+    int rc = build_scene(*sc, *desc);
+    if (rc == RTX_OK) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) sc->cus = prop.multiProcessorCount;
+        // device address of this GPU's copy of the no-allocation scratch array (first scene on the device)
+        unsigned char* at = nullptr;
+        if (device < RTX_MAX_DEVICES) {
+            const hipError_t e = scratch_address(device, &at);
+            if (e != hipSuccess) rc = fail(RTX_EHIP, std::string("hipGetSymbolAddress(scratch): ") + hipGetErrorString(e));
+        }
+    }
+    // the frame context behind rtx_render and rtx_render_noalloc
+    if (rc == RTX_OK) rc = frame_create(sc, &sc->own);
+    if (rc != RTX_OK) { if (sc->own) frame_destroy(sc->own); delete sc; return rc; }
+    *out = sc;
+    return RTX_OK;
+}
+
+int rtx_scene_update_lights(rtx_scene* sc, const rtx_light* lights, int32_t n_lights) {
+    if (!sc || n_lights < 0 || (n_lights > 0 && !lights)) return fail(RTX_EINVAL, "bad argument");
+    HIP_TRY(hipSetDevice(sc->device));
+    std::vector<Light> l((size_t)n_lights);
+    for (int i = 0; i < n_lights; i++) { memcpy(l[(size_t)i].p, lights[i].position, 24); memcpy(l[(size_t)i].i, lights[i].intensity, 24); }
+    // A new version: frames in flight keep the one they were submitted with.  A version that no
+    // frame and not the scene holds any more is written over instead of allocating another.
+    std::lock_guard<std::mutex> lock(sc->lights_mutex);
+    std::shared_ptr<LightSet> ls;
+    for (auto& p : sc->light_pool)
+        if (p.use_count() == 1) { ls = p; break; }
+    if (!ls) { ls = std::make_shared<LightSet>(); sc->light_pool.push_back(ls); }
+    HIP_TRY(ls->buf.upload(l));          // (blocking copy: complete before any frame can be submitted with it)
+    ls->n = n_lights;
+    sc->lights = ls;
+    sc->dev.lights = (const Light*)ls->buf.p;
+    sc->dev.n_lights = n_lights;
+    return RTX_OK;
+}
+
+int rtx_scene_set_counters(rtx_scene* sc, int32_t enable) {
+    if (!sc) return fail(RTX_EINVAL, "null scene");
+    sc->counters_on = enable != 0;
+    return RTX_OK;
+}
+
+int rtx_scene_set_consistent(rtx_scene* sc, int32_t enable) {
+    if (!sc) return fail(RTX_EINVAL, "null scene");
+    sc->consistent = enable != 0;
+    return RTX_OK;
+}
+
+int rtx_scene_set_generation_timing(rtx_scene* sc, int32_t enable) {
+    if (!sc) return fail(RTX_EINVAL, "null scene");
+    sc->generation_timing = enable != 0;
+    return RTX_OK;
+}
+
+int rtx_scene_set_queue_limit(rtx_scene* sc, int64_t bytes) {
+    if (!sc || bytes < (int64_t)(1 << 20)) return fail(RTX_EINVAL, "bad queue limit");
+    sc->queue_limit = bytes;
+    return RTX_OK;
+}
+
+int rtx_scene_set_debug(rtx_scene* sc, uint32_t flags) {
+    if (!sc) return fail(RTX_EINVAL, "null scene");
+    if (flags & ~(uint32_t)RTX_DEBUG_ALL) return fail(RTX_EINVAL, "unknown debug flag");
+    sc->debug = flags;
+    return RTX_OK;
+}
+
+void rtx_scene_destroy(rtx_scene* sc) {
+    if (!sc) return;
+    (void)hipSetDevice(sc->device);
+    // frames the caller has not destroyed go with the scene (their handles are dead from here on)
+    while (true) {
+        rtx_frame* fr = nullptr;
+        {
+            std::lock_guard<std::mutex> lock(sc->frames_mutex);
+            if (!sc->frames.empty()) fr = sc->frames.back();
+        }
+        if (!fr) break;
+        frame_destroy(fr);
+    }
+    delete sc;
+}
+
+int rtx_frame_create(rtx_scene* sc, rtx_frame** out) {
+    if (!sc || !out) return fail(RTX_EINVAL, "null argument");
+    return frame_create(sc, out);
+}
+
+void rtx_frame_destroy(rtx_frame* fr) {
+    if (fr) frame_destroy(fr);
+}
+
+int rtx_render_async(rtx_frame* fr, const rtx_camera* cam, int32_t tw, int32_t th, int32_t first, int32_t stride,
+                     uint8_t* rgb_out, int32_t rgb_is_device, rtx_hit_id* hit_ids) {
+    return frame_submit(fr, cam, tw, th, first, stride, rgb_out, rgb_is_device, hit_ids, false);
+}
+
+int rtx_frame_wait(rtx_frame* fr, rtx_stats* stats) {
+    return frame_wait(fr, stats);
+}
+
 int rtx_render(rtx_scene* sc, const rtx_camera* cam, int32_t tw, int32_t th, int32_t first, int32_t stride,
                uint8_t* rgb_out, int32_t rgb_is_device, rtx_hit_id* hit_ids, rtx_stats* stats) {
-    return render_frame(sc, cam, tw, th, first, stride, rgb_out, rgb_is_device, hit_ids, stats, false);
+    if (!sc) return fail(RTX_EINVAL, "null argument");
+    if (stats) memset(stats, 0, sizeof *stats);
+    const int rc = frame_submit(sc->own, cam, tw, th, first, stride, rgb_out, rgb_is_device, hit_ids, false);
+    if (rc) return rc;
+    return frame_wait(sc->own, stats);
 }
 
 int rtx_render_noalloc(rtx_scene* sc, const rtx_camera* cam, int32_t tw, int32_t th, int32_t first, int32_t stride,
                        uint8_t* rgb_out, int32_t rgb_is_device, rtx_stats* stats) {
-    return render_frame(sc, cam, tw, th, first, stride, rgb_out, rgb_is_device, nullptr, stats, true);
+    if (!sc) return fail(RTX_EINVAL, "null argument");
+    if (stats) memset(stats, 0, sizeof *stats);
+    const int rc = frame_submit(sc->own, cam, tw, th, first, stride, rgb_out, rgb_is_device, nullptr, true);
+    if (rc) return rc;
+    return frame_wait(sc->own, stats);
 }
 
 int64_t rtx_noalloc_scratch_bytes(void) { return (int64_t)RTX_NOALLOC_SCRATCH_BYTES; }

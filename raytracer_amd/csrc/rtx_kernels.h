@@ -1323,7 +1323,10 @@ RTX_DEV void service_lane(const Launch* __restrict__ Lp, const ObjCache& oc, con
             if (L.btri >= 0) L.hit = 1;
             L.t_min = oc.ctx[0];
         } else {
-            job_finalize<FAST, NEST>(S, oc, L, out);
+            // (the search's own rays are finalised by search_service; what arrives here with NEST = 2 is
+            // a mesh job or a ray handed back to the index-order replay, whose L.whi is the last summary
+            // word of its candidate bitmap: no nearest-first tie-break, which would overwrite it)
+            job_finalize<FAST, NEST == 1 ? 1 : 0>(S, oc, L, out);
         }
         if (nested && nest == -1) nest = 2;
         L.state = LS_NEED_JOB;

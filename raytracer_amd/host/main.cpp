@@ -21,11 +21,12 @@
 //     (the reference splits a frame into row bands over its threads, raytracer.cpp:107-126;
 //     interleaved tiles balance scenes whose geometry sits in one strip).  A device may be named
 //     more than once (two tile streams on one GPU).
-// --inflight K  K frames of an animation in flight at once (default 2): K pipelines, each with its own
-//     loaded scene, device copy and host thread, take the frames in turn.  The last ray
-//     generations of a frame are a few long rays in an otherwise idle GPU; the next frame's full
-//     generations run beside them (camera_around_david stand-in on one MI355X: 2.4 -> 1.5 ms per frame
-//     with three in flight).
+// --inflight K  up to K pictures in flight at once (default 3) on ONE loaded scene and ONE device copy
+//     of it: K frame contexts (rtx_frame_create) of the device scene take the cameras and animation
+//     frames in turn, each submitted without waiting (rtx_render_async) and collected when its turn
+//     comes round again.  The last ray generations of a frame are a few long rays in an otherwise
+//     idle GPU; the next frame's full generations run beside them.  Geometry is uploaded once; a
+//     frame keeps the lights that were current when it was submitted.
 // --resolution WxH  render every camera at this resolution instead of the scene file's
 //     ImageResolution (same view: keep the aspect ratio).
 //
@@ -130,7 +131,7 @@ int main(int argc, char** argv) {
     bool use_bvh = true, cull = false, multithreaded = true, png = false, quiet = false, gpu_build = false, consistent = false;
     int device = 0, shard_r = 0, shard_n = 1;
     std::vector<int> devices;
-    int tile_w = 64, tile_h = 8, res_w = 0, res_h = 0, inflight = 2;
+    int tile_w = 64, tile_h = 8, res_w = 0, res_h = 0, inflight = 3;
     std::string out_dir = "../my_outputs_hw2/";            // raytracer.cpp:13
     auto opt01 = [&](int& i, bool bare_value, bool& target) {
         if (i + 1 < argc && (!strcmp(argv[i + 1], "0") || !strcmp(argv[i + 1], "1"))) { target = atoi(argv[++i]) != 0; }
@@ -166,22 +167,95 @@ int main(int argc, char** argv) {
     if (devices.empty()) devices.push_back(device);
     device = devices[0];
     const int n_dev = (int)devices.size();
-    std::atomic<int> rc_all{0};
+    int rc_all = 0;
     Writer writer;
-    // this process's frames, dealt to the pipelines in turn
-    std::vector<size_t> mine;
-    for (size_t si = 0; si < scenes.size(); si++)
-        if ((int)(si % (size_t)shard_n) == shard_r) mine.push_back(si);
-    const int n_pipes = (int)std::max<size_t>(1, std::min<size_t>((size_t)inflight, mine.size()));
-    auto pipeline = [&](const int pipe) {
+
     rtx_host_scene* hs = nullptr;
     std::vector<rtx_scene*> ds;                 // the scene on every device taking part
-    auto drop_device_scenes = [&ds] { for (rtx_scene* d : ds) rtx_scene_destroy(d); ds.clear(); };
+    // A picture in flight: one frame context per device (one device: the whole picture; several: that
+    // device's interleaved tiles, packed), and what is needed to finish it when its turn comes again.
+    struct Slot {
+        std::vector<rtx_frame*> fr;
+        std::vector<std::vector<uint8_t>> packed;
+        OutputJob job;
+        rtx_camera cam{};
+        std::string scene_file, name;
+        double parse_ms = 0, pre_ms = 0, upload_ms = 0;
+        bool reused = false, busy = false;
+        size_t file = 0;
+        std::chrono::high_resolution_clock::time_point t0;
+    };
+    std::vector<Slot> slots((size_t)inflight);
+    size_t next_slot = 0;
+    std::vector<double> file_ms(scenes.size(), 0.0);   // (the reference's totalTimeMs accumulates over a file's cameras, raytracer.cpp:260)
+
+    // Wait for a slot's picture and hand it to the writer.
+    auto collect = [&](Slot& sl) {
+        if (!sl.busy) return;
+        sl.busy = false;
+        rtx_stats st;
+        memset(&st, 0, sizeof st);
+        bool ok = true;
+        for (int r = 0; r < n_dev; r++) {
+            rtx_stats part;
+            if (n_dev > 1 && sl.packed[(size_t)r].empty()) continue;       // (more devices than tiles)
+            if (rtx_frame_wait(sl.fr[(size_t)r], &part) != RTX_OK) {
+                fprintf(stderr, "%s: device %d: %s\n", sl.scene_file.c_str(), devices[(size_t)r], rtx_last_error());
+                ok = false;
+                continue;
+            }
+            if (n_dev > 1 && rtx_unpack_tiles(sl.packed[(size_t)r].data(), sl.cam.width, sl.cam.height, tile_w, tile_h, r, n_dev,
+                                              sl.job.img.data()) != RTX_OK) {
+                fprintf(stderr, "%s: %s\n", sl.scene_file.c_str(), rtx_last_error());
+                ok = false;
+            }
+            st.rays += part.rays; st.primary_rays += part.primary_rays;
+            st.shadow_rays += part.shadow_rays; st.secondary_rays += part.secondary_rays;
+            st.kernel_ms = std::max(st.kernel_ms, part.kernel_ms);
+        }
+        if (!ok) { rc_all = 1; return; }
+        // submit -> picture complete (with pictures in flight this spans the neighbours' work too)
+        st.total_ms = std::chrono::duration<double, std::milli>(std::chrono::high_resolution_clock::now() - sl.t0).count();
+        file_ms[sl.file] += st.total_ms;
+        OutputJob& job = sl.job;
+        job.base = out_dir + sl.name;
+        job.stem = job.base.substr(0, job.base.find_last_of('.'));
+        job.width = sl.cam.width; job.height = sl.cam.height; job.png = png;
+        char buf[1536];
+        snprintf(buf, sizeof buf,
+                 "{\n    \"enableBackFaceCulling\": %s,\n    \"isMultiThreaded\": %s,\n"
+                 "    \"preprocessingTimeMs\": %.3f,\n    \"renderTimeMs\": %.3f,\n    \"sceneName\": \"%s\",\n"
+                 "    \"totalTimeMs\": %.3f,\n    \"useBVH\": %s,\n    \"device\": \"hip:%d\",\n"
+                 "    \"kernelTimeMs\": %.3f,\n    \"parseTimeMs\": %.3f,\n    \"uploadTimeMs\": %.3f,\n"
+                 "    \"geometryReused\": %s,\n    \"nGpus\": %d,\n    \"framesInFlight\": %d,\n    \"rays\": %llu,\n    \"MraysPerS\": %.3f,\n"
+                 "    \"width\": %d,\n    \"height\": %d\n}",
+                 cull ? "true" : "false", multithreaded ? "true" : "false", sl.pre_ms, st.total_ms, sl.name.c_str(), sl.pre_ms + file_ms[sl.file],
+                 use_bvh ? "true" : "false", device, st.kernel_ms, sl.parse_ms, sl.upload_ms, sl.reused ? "true" : "false",
+                 n_dev, inflight, (unsigned long long)st.rays, st.total_ms > 0 ? (double)st.rays / st.total_ms / 1e3 : 0.0,
+                 sl.cam.width, sl.cam.height);
+        job.results = buf;
+        if (!quiet)
+            printf("%s: %dx%d rendered in %.3f ms (kernels %.3f ms), parse %.1f ms, preprocess %.1f ms, upload %.1f ms%s\n",
+                   sl.name.c_str(), sl.cam.width, sl.cam.height, st.total_ms, st.kernel_ms, sl.parse_ms, sl.pre_ms, sl.upload_ms,
+                   sl.reused ? " (geometry kept)" : "");
+        writer.push(std::move(job));
+        sl.job = OutputJob();
+    };
+    auto drain = [&] { for (size_t k = 0; k < slots.size(); k++) collect(slots[(next_slot + k) % slots.size()]); };
+    auto drop_device_scenes = [&] {
+        drain();
+        for (Slot& sl : slots) { for (rtx_frame* f : sl.fr) rtx_frame_destroy(f); sl.fr.clear(); }
+        for (rtx_scene* d : ds) rtx_scene_destroy(d);
+        ds.clear();
+    };
+
     double upload_ms = 0;
-    for (size_t mi = (size_t)pipe; mi < mine.size(); mi += (size_t)n_pipes) {
-        const size_t si = mine[mi];
+    for (size_t si = 0; si < scenes.size(); si++) {
+        if ((int)(si % (size_t)shard_n) != shard_r) continue;
         int reused = 0;
         if (hs) {
+            // (pictures in flight read nothing of the host scene: the device has its own copy, and a
+            // frame holds its camera and its version of the lights)
             rtx_host_scene* next = nullptr;
             if (rtx_host_load_next(scenes[si].c_str(), hs, &next, &reused) != 0) {
                 fprintf(stderr, "%s: %s\n", scenes[si].c_str(), rtx_host_last_error());
@@ -234,102 +308,67 @@ int main(int argc, char** argv) {
         } else {
             drop_device_scenes();
             auto t0 = std::chrono::high_resolution_clock::now();
-            for (int k = 0; k < n_dev; k++) {
+            bool ok = true;
+            for (int k = 0; k < n_dev && ok; k++) {
                 rtx_scene* d = nullptr;
-                if (rtx_scene_create(desc, devices[(size_t)k], &d) != RTX_OK) {
-                    fprintf(stderr, "%s: %s\n", scenes[si].c_str(), rtx_last_error());
-                    drop_device_scenes();
-                    rtx_host_free(hs);
-                    rc_all = 1;
-                    return;                                  // no device: nothing else can work either
+                ok = rtx_scene_create(desc, devices[(size_t)k], &d) == RTX_OK;
+                if (ok) {
+                    if (consistent) rtx_scene_set_consistent(d, 1);
+                    rtx_scene_set_generation_timing(d, 0);       // (the results file does not report per-generation times)
+                    ds.push_back(d);
                 }
-                if (consistent) rtx_scene_set_consistent(d, 1);
-                rtx_scene_set_generation_timing(d, 0);       // (the results file does not report per-generation times)
-                ds.push_back(d);
+            }
+            for (Slot& sl : slots)
+                for (int k = 0; k < n_dev && ok; k++) {
+                    rtx_frame* f = nullptr;
+                    ok = rtx_frame_create(ds[(size_t)k], &f) == RTX_OK;
+                    if (ok) sl.fr.push_back(f);
+                }
+            if (!ok) {
+                fprintf(stderr, "%s: %s\n", scenes[si].c_str(), rtx_last_error());
+                drop_device_scenes();
+                rtx_host_free(hs);
+                writer.finish();
+                return 1;                                    // no device: nothing else can work either
             }
             upload_ms = std::chrono::duration<double, std::milli>(std::chrono::high_resolution_clock::now() - t0).count();
         }
-        double total_ms = pre_ms;
         for (int k = 0; k < rtx_host_camera_count(hs); k++) {
-            rtx_camera cam;
+            Slot& sl = slots[next_slot];
+            next_slot = (next_slot + 1) % slots.size();
+            collect(sl);                                     // the picture this slot was busy with
             char name[512];
-            rtx_host_camera(hs, k, &cam, name, sizeof name);
-            if (res_w > 0) { cam.width = res_w; cam.height = res_h; }
-            OutputJob job;
-            job.img.resize((size_t)cam.width * cam.height * 3);
-            rtx_stats st;
+            rtx_host_camera(hs, k, &sl.cam, name, sizeof name);
+            if (res_w > 0) { sl.cam.width = res_w; sl.cam.height = res_h; }
+            sl.name = name; sl.scene_file = scenes[si]; sl.file = si;
+            sl.parse_ms = parse_ms; sl.pre_ms = pre_ms; sl.upload_ms = upload_ms; sl.reused = reused != 0;
+            sl.job.img.resize((size_t)sl.cam.width * sl.cam.height * 3);
+            sl.t0 = std::chrono::high_resolution_clock::now();
+            bool ok = true;
             if (n_dev == 1) {
-                if (rtx_render(ds[0], &cam, cam.width, cam.height, 0, 1, job.img.data(), 0, nullptr, &st) != RTX_OK) {
-                    fprintf(stderr, "%s: %s\n", scenes[si].c_str(), rtx_last_error());
-                    rc_all = 1;
-                    break;
-                }
+                ok = rtx_render_async(sl.fr[0], &sl.cam, sl.cam.width, sl.cam.height, 0, 1, sl.job.img.data(), 0, nullptr) == RTX_OK;
             } else {
-                // one host thread per device: its interleaved tiles into a packed buffer of its own
-                auto t0 = std::chrono::high_resolution_clock::now();
-                std::vector<std::vector<uint8_t>> packed((size_t)n_dev);
-                std::vector<rtx_stats> part((size_t)n_dev);
-                std::vector<std::string> errors((size_t)n_dev);
-                std::vector<std::thread> workers;
-                for (int r = 0; r < n_dev; r++) {
-                    const int64_t bytes = rtx_render_output_bytes(&cam, tile_w, tile_h, r, n_dev);
-                    packed[(size_t)r].resize((size_t)std::max<int64_t>(bytes, 0));
-                    workers.emplace_back([&, r] {
-                        memset(&part[(size_t)r], 0, sizeof(rtx_stats));
-                        if (packed[(size_t)r].empty()) return;
-                        if (rtx_render(ds[(size_t)r], &cam, tile_w, tile_h, r, n_dev, packed[(size_t)r].data(), 0, nullptr,
-                                       &part[(size_t)r]) != RTX_OK)
-                            errors[(size_t)r] = rtx_last_error();      // (the error text is per thread)
-                    });
+                // every device its interleaved tiles into a packed buffer of its own, all submitted before any is waited for
+                sl.packed.resize((size_t)n_dev);
+                for (int r = 0; r < n_dev && ok; r++) {
+                    const int64_t bytes = rtx_render_output_bytes(&sl.cam, tile_w, tile_h, r, n_dev);
+                    sl.packed[(size_t)r].resize((size_t)std::max<int64_t>(bytes, 0));
+                    if (sl.packed[(size_t)r].empty()) continue;
+                    ok = rtx_render_async(sl.fr[(size_t)r], &sl.cam, tile_w, tile_h, r, n_dev, sl.packed[(size_t)r].data(), 0, nullptr) == RTX_OK;
                 }
-                for (std::thread& t : workers) t.join();
-                bool ok = true;
-                memset(&st, 0, sizeof st);
-                for (int r = 0; r < n_dev; r++) {
-                    if (!errors[(size_t)r].empty()) { fprintf(stderr, "%s: device %d: %s\n", scenes[si].c_str(), devices[(size_t)r], errors[(size_t)r].c_str()); ok = false; continue; }
-                    if (!packed[(size_t)r].empty() &&
-                        rtx_unpack_tiles(packed[(size_t)r].data(), cam.width, cam.height, tile_w, tile_h, r, n_dev, job.img.data()) != RTX_OK) {
-                        fprintf(stderr, "%s: %s\n", scenes[si].c_str(), rtx_last_error());
-                        ok = false;
-                    }
-                    st.rays += part[(size_t)r].rays; st.primary_rays += part[(size_t)r].primary_rays;
-                    st.shadow_rays += part[(size_t)r].shadow_rays; st.secondary_rays += part[(size_t)r].secondary_rays;
-                    st.kernel_ms = std::max(st.kernel_ms, part[(size_t)r].kernel_ms);
-                }
-                if (!ok) { rc_all = 1; break; }
-                st.total_ms = std::chrono::duration<double, std::milli>(std::chrono::high_resolution_clock::now() - t0).count();
             }
-            total_ms += st.total_ms;
-            job.base = out_dir + name;
-            job.stem = job.base.substr(0, job.base.find_last_of('.'));
-            job.width = cam.width; job.height = cam.height; job.png = png;
-            char buf[1536];
-            snprintf(buf, sizeof buf,
-                     "{\n    \"enableBackFaceCulling\": %s,\n    \"isMultiThreaded\": %s,\n"
-                     "    \"preprocessingTimeMs\": %.3f,\n    \"renderTimeMs\": %.3f,\n    \"sceneName\": \"%s\",\n"
-                     "    \"totalTimeMs\": %.3f,\n    \"useBVH\": %s,\n    \"device\": \"hip:%d\",\n"
-                     "    \"kernelTimeMs\": %.3f,\n    \"parseTimeMs\": %.3f,\n    \"uploadTimeMs\": %.3f,\n"
-                     "    \"geometryReused\": %s,\n    \"nGpus\": %d,\n    \"rays\": %llu,\n    \"MraysPerS\": %.3f,\n"
-                     "    \"width\": %d,\n    \"height\": %d\n}",
-                     cull ? "true" : "false", multithreaded ? "true" : "false", pre_ms, st.total_ms, name, total_ms,
-                     use_bvh ? "true" : "false", device, st.kernel_ms, parse_ms, upload_ms, reused ? "true" : "false",
-                     n_dev, (unsigned long long)st.rays, st.total_ms > 0 ? (double)st.rays / st.total_ms / 1e3 : 0.0,
-                     cam.width, cam.height);
-            job.results = buf;
-            writer.push(std::move(job));
-            if (!quiet)
-                printf("%s: %dx%d rendered in %.3f ms (kernels %.3f ms), parse %.1f ms, preprocess %.1f ms, upload %.1f ms%s\n",
-                       name, cam.width, cam.height, st.total_ms, st.kernel_ms, parse_ms, pre_ms, upload_ms,
-                       reused ? " (geometry kept)" : "");
+            if (!ok) {
+                fprintf(stderr, "%s: %s\n", scenes[si].c_str(), rtx_last_error());
+                rc_all = 1;
+                // (frames of this picture that were submitted are waited for and dropped)
+                for (int r = 0; r < n_dev; r++) { rtx_stats st; (void)rtx_frame_wait(sl.fr[(size_t)r], &st); }
+                break;
+            }
+            sl.busy = true;
         }
     }
     drop_device_scenes();
     if (hs) rtx_host_free(hs);
-    };
-    std::vector<std::thread> pipes;
-    for (int p = 1; p < n_pipes; p++) pipes.emplace_back(pipeline, p);
-    pipeline(0);
-    for (std::thread& t : pipes) t.join();
     if (!writer.finish()) rc_all = 1;
     return rc_all;
 }

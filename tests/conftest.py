@@ -19,3 +19,15 @@ def unit_scenes(tmp_path_factory):
     from raytracer_amd import scenes
     d = tmp_path_factory.mktemp("unit_scenes")
     return scenes.write_unit_scenes(str(d))
+
+
+@pytest.fixture(scope="session")
+def torch_warm():
+    """The first `import torch` on a fresh machine pages the library in for a minute or two.  Tests that
+    start a child process which imports torch ask for this fixture: it pays that once, in a child of
+    its own with a generous limit, so that the tests' own limits measure their work and a test that
+    runs into one has failed (not: is skipped)."""
+    import subprocess
+    r = subprocess.run([sys.executable, "-c", "import torch; print(torch.__version__)"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    return r.stdout.strip()

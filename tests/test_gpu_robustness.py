@@ -16,22 +16,22 @@ from raytracer_amd.scenes import _camera, _dump, _flat, _light, _mat
 pytestmark = pytest.mark.gpu
 
 
-def test_overflowing_frame_with_dirty_queues(tmp_path, monkeypatch):
+def test_overflowing_frame_with_dirty_queues(tmp_path):
     """The queues are sized by a small first frame; a larger one overflows them.  With the
     queue and hit-record memory filled with 0xFF beforehand, slots the overflowed attempt
     reserved but never wrote hold garbage: no kernel may consume them."""
-    monkeypatch.setenv("RTX_AMD_POISON_QUEUES", "1")
     path = scenes.scene_tiny(str(tmp_path), res=(16, 12))
     hs = rt.HostScene(path)
     ds = rt.DeviceScene(hs.desc, 0)
+    ds.set_debug(_abi.DEBUG_POISON_QUEUES)
     cam, _ = hs.camera(0)
     ds.render(cam)
     big = type(cam).from_buffer_copy(cam)
     big.width, big.height = 400, 300
     rgb, hits, st = ds.render(big, want_hits=True)
     assert st["queue_overflows"] >= 1
-    monkeypatch.delenv("RTX_AMD_POISON_QUEUES")
     fresh = rt.DeviceScene(hs.desc, 0)
+    fresh.set_debug(0)
     rgb2, hits2, st2 = fresh.render(big, want_hits=True)
     assert st2["queue_overflows"] == 0
     assert np.array_equal(hits, hits2)

@@ -10,19 +10,19 @@ import pytest
 
 import _checkers as ck
 import raytracer_amd as rt
-from raytracer_amd import scenes
+from raytracer_amd import _abi, scenes
 
 pytestmark = pytest.mark.gpu
 
 
 def _both_ways(ds, cam):
-    os.environ.pop("RTX_AMD_NO_SEARCH", None)
+    ds.set_debug(0)
     a = ds.render(cam, want_hits=True)
-    os.environ["RTX_AMD_NO_SEARCH"] = "1"          # (read per frame by the library: development switch)
+    ds.set_debug(_abi.DEBUG_NO_SEARCH)             # the index-order replay the search stands in for
     try:
         b = ds.render(cam, want_hits=True)
     finally:
-        os.environ.pop("RTX_AMD_NO_SEARCH", None)
+        ds.set_debug(0)
     return a, b
 
 
