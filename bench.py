@@ -47,6 +47,9 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0        # HBM3E, spec
 L2_PEAK_GBS = 34500.0        # 8 x 4 MiB L2, aggregate
+L2_GATHER_GBS = 17800.0      # whole records gathered into LDS out of an XCD's L2: 16.8-18.8 TB/s measured chip-wide
+L2_BYTES = 32 << 20          # 8 x 4 MiB
+PROFILE_ROUND = "r03"        # the committed profiles this build's line quotes (profiles/<round>_<workload>_*.json)
 FP64_VALU_PEAK_TF = 78.6     # vector FP64 (what the path computes in)
 FP32_VALU_PEAK_TF = 157.3    # vector FP32
 SEQUENCE_FRAMES = 360
@@ -80,6 +83,12 @@ def launch_ranks(n: int, argv, script=None, python=None, extra_env=None) -> int:
         env.update(extra_env or {})
         procs.append(subprocess.Popen([python, script] + list(argv), env=env,
                                       stdout=subprocess.PIPE if r == 0 else sys.stderr))
+    # rank 0's line is read while the ranks run: a line longer than the pipe's buffer would otherwise
+    # block rank 0 in its write, and with it every rank waiting for rank 0 in a collective
+    import threading
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
     rc = 0
     pending = set(range(n))
     while pending:
@@ -95,7 +104,8 @@ def launch_ranks(n: int, argv, script=None, python=None, extra_env=None) -> int:
                     procs[q].terminate()
         if pending:
             time.sleep(0.05)
-    out = procs[0].stdout.read().decode(errors="replace")
+    reader.join(timeout=30)
+    out = b"".join(chunks).decode(errors="replace")
     sys.stdout.write(out)
     sys.stdout.flush()
     return rc
@@ -116,9 +126,18 @@ def selftest_rank(args) -> int:
     t = torch.tensor([float(rank + 1)])
     if world > 1:
         dist.all_reduce(t)
+    # the self-checks of a real N > 1 line, on stand-in data: every rank is seen by the collective,
+    # per-rank step times are gathered, and a frame every rank "renders" hashes alike on all of them
+    import numpy as np
+    R = Rank.__new__(Rank)
+    R.torch, R.world, R.rank, R.dist, R.red_dev, R.backend = torch, world, rank, (dist if world > 1 else None), "cpu", "gloo"
+    frame = (np.arange(4096, dtype=np.uint32) * 2654435761 % 251).astype(np.uint8)
+    if args.selftest_differ_rank == rank:
+        frame[17] ^= 1
+    check = multi_rank_check(R, frame, ms_per_step=1.0 + rank)
     if rank == 0:
         print(json.dumps({"selftest": True, "n_gpus": world, "rank_sum": float(t.item()),
-                          "local_rank_env": os.environ.get("LOCAL_RANK")}), flush=True)
+                          "local_rank_env": os.environ.get("LOCAL_RANK"), "multi_gpu": check}), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -445,6 +464,7 @@ class Rank:
         torch.cuda.set_device(self.local_rank)
         self.red_dev = "cpu" if self.rehearsal else "cuda"
         self.dist = None
+        self.backend = None
         if self.world > 1:
             import torch.distributed as dist
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -453,6 +473,7 @@ class Rank:
             else:
                 dist.init_process_group("nccl", device_id=torch.device("cuda", self.local_rank))
             self.dist = dist
+            self.backend = dist.get_backend()
         self.host_threads = max(1, min(16, os.cpu_count() or 1) // max(self.world, 1))
 
     def barrier(self):
@@ -488,27 +509,67 @@ class Rank:
             self.dist.destroy_process_group()
 
 
+def frame_hash(frame) -> int:
+    """63-bit hash of a picture's bytes (blake2b), for comparing pictures between ranks."""
+    import hashlib
+    import numpy as np
+    h = hashlib.blake2b(np.ascontiguousarray(frame).tobytes(), digest_size=8).digest()
+    return int.from_bytes(h, "little") & 0x7FFFFFFFFFFFFFFF
+
+
+def multi_rank_check(R, frame, ms_per_step):
+    """What lets a reader check an N > 1 line without the hardware: the backend of the process
+    group, the number of ranks the collective saw (an all-reduce of ones; the run fails if it is
+    not N), every rank's own time per step, and whether `frame` -- a picture every rank rendered
+    from the same camera -- is the same bytes on every rank (an all-gather of 63-bit hashes)."""
+    torch = R.torch
+    seen = int(round(R.reduce([1.0])[0]))
+    if seen != R.world:
+        raise SystemExit(f"rank {R.rank}: the collective saw {seen} ranks, expected {R.world}")
+    mine = torch.tensor([frame_hash(frame)], dtype=torch.int64, device=R.red_dev)
+    per = torch.tensor([float(ms_per_step)], dtype=torch.float64, device=R.red_dev)
+    if R.dist is not None:
+        hashes = [torch.zeros_like(mine) for _ in range(R.world)]
+        times = [torch.zeros_like(per) for _ in range(R.world)]
+        R.dist.all_gather(hashes, mine)
+        R.dist.all_gather(times, per)
+    else:
+        hashes, times = [mine], [per]
+    hashes = [int(h.item()) for h in hashes]
+    times = [float(t.item()) for t in times]
+    return {"backend": R.backend, "ranks_seen": seen, "ms_per_step_per_rank": times,
+            "ms_per_step_min": min(times), "ms_per_step_max": max(times),
+            "frames_identical_across_ranks": all(h == hashes[0] for h in hashes),
+            "frame_hashes": [f"{h:016x}" for h in hashes]}
+
+
 def timed(R: Rank, step, steps, warmup):
     """warmup untimed steps, then exactly `steps` steps between barrier + synchronize on both
-    sides -> (elapsed seconds, max over ranks; list of the steps' rtx_stats)."""
+    sides -> (elapsed seconds, max over ranks; list of the steps' rtx_stats; this rank's own seconds)."""
     for i in range(warmup):
         step(i - warmup)
     R.barrier()
     t0 = time.perf_counter()
     stats = [step(i) for i in range(steps)]
+    mine = time.perf_counter() - t0            # (this rank's own K steps, before it waits for the others)
     R.barrier()
     elapsed = time.perf_counter() - t0
-    return R.reduce([elapsed], "max")[0], stats
+    return R.reduce([elapsed], "max")[0], stats, mine
 
 
 def pmc_summary(workload):
-    """Hardware-counter figures of the trace kernel from the committed profile of this workload
-    (profiles/r02_<workload>_pmc.json, written by tools/pmc_to_json.py from separate rocprofv3
-    --pmc passes over this same bench), or None."""
-    p = os.path.join(ROOT, "profiles", f"r02_{workload}_pmc.json")
+    """Hardware-counter figures of the TIMED trace-kernel variant from the committed profile of this
+    workload (profiles/<round>_<workload>_pmc.json, written by tools/pmc_to_json.py from separate
+    rocprofv3 --pmc passes over this same bench; per kernel variant, so that the counters-on variant of
+    the untimed counting pass is not mixed in), or None.  The object names the build the profile was
+    taken from: these figures are copied from the file, not measured in this run."""
+    p = os.path.join(ROOT, "profiles", f"{PROFILE_ROUND}_{workload}_pmc.json")
     try:
         with open(p) as f:
-            return json.load(f)
+            j = json.load(f)
+        v = j["variants"][j["timed_variant"]]
+        return {"source": f"profiles/{PROFILE_ROUND}_{workload}_pmc.json (build {j.get('build', '?')}; copied from that file, "
+                          "not measured in this run)", "kernel": j["timed_variant"], **v}
     except Exception:
         return None
 
@@ -551,7 +612,7 @@ def measure_static(R: Rank, args, name, mode, steps, warmup, with_cpu, pipelined
     sample_f = cpu_sample_factor(hs.desc, cam)
     ref_counts = o_rgb = o_hits = None
     ocam = cam
-    if mode == "frames" and (rank == 0 or world == 1):
+    if rank == 0:
         if sample_f > 1:
             # the view the bounded CPU legs render: the camera of the scene file with its resolution
             # reduced (the reference derives the near plane from the file's own aspect ratio), so that
@@ -610,37 +671,45 @@ def measure_static(R: Rank, args, name, mode, steps, warmup, with_cpu, pipelined
             gatherer.run(render_tiles)
             return last["st"]
     R.note("timed steps")
-    elapsed, stats = timed(R, step, steps, warmup)
-    # Two frames in flight per GPU (throughput of a stream of frames rather than the latency of
-    # one): a second device copy of the scene and a second host thread, each rendering `steps`
-    # frames back to back; one frame's thin last generations overlap the other's full ones.
+    elapsed, stats, elapsed_mine = timed(R, step, steps, warmup)
+    # Several frames in flight per GPU (throughput of a stream of frames rather than the latency of
+    # one): frame contexts of the ONE device scene (rtx_frame_create), each frame submitted without
+    # waiting (rtx_render_async) and collected when its context's turn comes round again; one frame's
+    # thin last generations overlap the next ones' full generations.  Every frame of the turntable is
+    # rendered k_fl times in all.
     piped = None
     if pipelined and mode == "frames":
-        import threading
         k_fl = args.inflight if args.inflight > 1 else 3
-        extra = [(rt.DeviceScene(hs.desc, R.local_rank), R.pinned(cam.height * cam.width * 3).reshape(cam.height, cam.width, 3))
-                 for _ in range(k_fl - 1)]
-        for d, f in extra:
-            d.render(cam, out=f)
+        ds.set_generation_timing(False)      # (as the command line's pipeline runs: no event pairs round the generations)
+        slots = [(ds.frame(), R.pinned(cam.height * cam.width * 3).reshape(cam.height, cam.width, 3)) for _ in range(k_fl)]
+        order = [turntable_frame(i, rank, world, steps) for i in range(steps)]
 
-        def burst(d, f, k):
-            # (each pipeline renders the whole turntable once, the pipelines a k-th of the way apart)
-            for i in range(steps):
-                d.render(turntable[turntable_frame(i + (k * steps) // k_fl, rank, world, steps)], out=f)
+        def stream(n):
+            q = []
+            for i in range(n):
+                fr, buf = slots[i % k_fl]
+                if len(q) == k_fl:
+                    q.pop(0).wait()
+                fr.submit(turntable[order[i % steps]], out=buf)
+                q.append(fr)
+            for fr in q:
+                fr.wait()
+        stream(k_fl)
         R.barrier()
         t0 = time.perf_counter()
-        threads = [threading.Thread(target=burst, args=(d, f, k + 1)) for k, (d, f) in enumerate(extra)]
-        for t in threads:
-            t.start()
-        burst(ds, frame, 0)
-        for t in threads:
-            t.join()
+        stream(k_fl * steps)
         R.barrier()
         el2 = R.reduce([time.perf_counter() - t0], "max")[0]
-        for d, _ in extra:
-            d.close()
-        piped = {"frames_in_flight_per_gpu": k_fl, "frames": k_fl * steps * world, "wall_s": el2,
-                 "ms_per_frame_per_gpu": el2 / (k_fl * steps) * 1e3}
+        # the last picture of every context against the blocking call's
+        same = True
+        for j, (fr, buf) in enumerate(slots):
+            i = k_fl * steps - k_fl + j
+            same = same and bool(np.array_equal(buf, ds.render(turntable[order[i % steps]])[0]))
+        for fr, _ in slots:
+            fr.close()
+        ds.set_generation_timing(True)
+        piped = {"frames_in_flight_per_gpu": k_fl, "device_scenes_per_gpu": 1, "frames": k_fl * steps * world, "wall_s": el2,
+                 "ms_per_frame_per_gpu": el2 / (k_fl * steps) * 1e3, "identical_to_blocking_render": same}
     # mode tiles: the assembled frame against the same frame rendered whole on rank 0
     tiles_identical = None
     if mode == "tiles" and rank == 0:
@@ -655,12 +724,20 @@ def measure_static(R: Rank, args, name, mode, steps, warmup, with_cpu, pipelined
     rays_frame = rays_timed_rank / steps              # this rank's mean frame
     # the scene file's own view alone (the frame the CPU reference is timed on and parity is checked on)
     view0_ms = None
+    if mode == "tiles":
+        view0_ms = elapsed / steps * 1e3          # (the tiled frame is the scene file's own view)
     if mode == "frames" and with_cpu:
         ds.render(cam0, out=frame)
         t0 = time.perf_counter()
         for _ in range(5):
             ds.render(cam0, out=frame)
         view0_ms = (time.perf_counter() - t0) / 5 * 1e3
+    multi = None
+    if world > 1 or args.multi_check:
+        # every rank renders one and the same view once, untimed, and the pictures' hashes are compared
+        # (tiles mode: the view at a quarter of the resolution, rendered whole)
+        ccam = cam0 if mode == "frames" else reduced_camera(cam0, 4)
+        multi = multi_rank_check(R, ds.render(ccam)[0], elapsed_mine / steps * 1e3)
     out = None
     if rank == 0:
         ms_per_step = elapsed / steps * 1e3
@@ -685,20 +762,28 @@ def measure_static(R: Rank, args, name, mode, steps, warmup, with_cpu, pipelined
         t_launch = avg_launch_ms * 1e-3
         achieved = bytes_per_launch / t_launch / 1e9 if t_launch > 0 else 0.0
         t_trace_frame = trace_ms / steps * 1e-3
-        traffic = None
-        for tfile in (os.path.join(ROOT, "profiles", f"r02_{name}_traffic.json"), os.path.join(ROOT, "profiles", "traffic.json")):
-            try:
-                with open(tfile) as f:
-                    tj = json.load(f)
-                if tj.get("workload") == name:
-                    traffic = tj.get("hbm_bytes_per_launch")
-                    break
-            except Exception:
-                continue
+        pmc = pmc_summary(name)
+        traffic = pmc.get("hbm_bytes_per_launch") if pmc else None
         tflops = flops / t_trace_frame / 1e12 if t_trace_frame > 0 else 0.0
+        # The stated bound: a scene whose records (nodes, triangles, object records) fit the L2s is
+        # served out of them, whatever the algorithmic byte count says -- HBM sees next to nothing of
+        # it (the counter traffic beside it shows that); a larger scene is priced against HBM.
+        working_set = ds.record_bytes()
+        l2_bound = 0 < working_set <= L2_BYTES
+        l2_rate = dev_b / t_trace_frame / 1e9 if t_trace_frame > 0 else 0.0
+        hbm = {"algorithmic_achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac_algorithmic": achieved / HBM_PEAK_GBS,
+               "measured_bytes_per_launch": traffic,
+               "measured_achieved": (traffic / t_launch / 1e9) if (traffic and t_launch > 0) else None,
+               "frac_measured": (traffic / t_launch / 1e9 / HBM_PEAK_GBS) if (traffic and t_launch > 0) else None,
+               "measured_source": pmc["source"] if pmc else None,
+               "note": "algorithmic bytes / kernel time against the HBM peak, and beside it the HBM-side bytes the counters "
+                       "saw (2 x FETCH_SIZE + WRITE_SIZE per launch of the timed variant) over this run's launch time"}
         roofline = {
-            "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+            "bound": "l2" if l2_bound else "hbm",
+            "achieved": l2_rate if l2_bound else achieved, "peak": L2_PEAK_GBS if l2_bound else HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": (l2_rate / L2_PEAK_GBS) if l2_bound else achieved / HBM_PEAK_GBS, "traffic": traffic,
+            "record_working_set_bytes": working_set,
+            "hbm": hbm,
             "kernel": "k_trace (closest-hit traversal; all variants of a generation)",
             "launches_per_frame": launches_per_frame, "avg_launch_ms": avg_launch_ms,
             "trace_ms_per_frame": trace_ms / steps, "all_kernels_ms_per_frame": kernel_ms / steps,
@@ -714,10 +799,12 @@ def measure_static(R: Rank, args, name, mode, steps, warmup, with_cpu, pipelined
             "instance_path": {0: "candidates replayed in index order", 1: "nearest-first search with verification (identical "
                               "results; rtx_kernels.h, search_service)", 2: "consistent mode's nearest-first walk"}.get(
                                   int(stats[-1].get("instance_path", 0)), "?"),
-            "l2": {"achieved": dev_b / t_trace_frame / 1e9 if t_trace_frame > 0 else 0.0, "peak": L2_PEAK_GBS,
-                   "unit": "GB/s", "frac": (dev_b / t_trace_frame / 1e9 / L2_PEAK_GBS) if t_trace_frame > 0 else 0.0,
+            "l2": {"achieved": l2_rate, "peak": L2_PEAK_GBS,
+                   "unit": "GB/s", "frac": l2_rate / L2_PEAK_GBS,
+                   "gather_peak": L2_GATHER_GBS, "frac_of_gather_peak": l2_rate / L2_GATHER_GBS,
                    "note": "device record bytes of the frame / trace time: the rate at which records leave the caches "
-                           "(most of them L2 or Infinity Cache hits), against the aggregate L2 bandwidth"},
+                           "(most of them L2 or Infinity Cache hits), against the aggregate L2 bandwidth and against the "
+                           "rate at which whole records can be gathered into LDS out of L2 (measured, 16.8-18.8 TB/s)"},
             "valu": {"flops_per_frame": flops, "achieved": tflops, "unit": "TFLOP/s",
                      "fp64_peak": FP64_VALU_PEAK_TF, "frac_fp64": tflops / FP64_VALU_PEAK_TF,
                      "fp32_peak": FP32_VALU_PEAK_TF, "frac_fp32": tflops / FP32_VALU_PEAK_TF,
@@ -735,7 +822,7 @@ def measure_static(R: Rank, args, name, mode, steps, warmup, with_cpu, pipelined
             "lanes_at_nodes_per_wave_step": cst["wave_inner_lanes"] / max(cst["wave_inner_steps"], 1),
             "lanes_at_leaves_per_wave_step": cst["wave_leaf_lanes"] / max(cst["wave_leaf_steps"], 1),
             "occupancy_waves_per_simd": 2,
-            "pmc": pmc_summary(name),
+            "pmc": pmc,
         }
         out = {
             "metric": "Mrays/s (ms/frame in ms_per_step)", "value": rays_step * steps / elapsed / 1e6, "unit": "Mrays/s",
@@ -760,17 +847,23 @@ def measure_static(R: Rank, args, name, mode, steps, warmup, with_cpu, pipelined
                                     if args.consistent else "reference-exact (default)"},
             "roofline": roofline,
         }
+        if multi is not None:
+            out["multi_gpu"] = multi
         if piped is not None:
             piped["Mrays_per_s"] = rays_step * piped["frames_in_flight_per_gpu"] * steps / piped["wall_s"] / 1e6
             out["frames_in_flight"] = piped
         if with_cpu:
             R.note("reference CPU renderer")
-            cb, ref_img = cpu_reference_baseline(path, rays_rank, sample_f)
+            cb, ref_img = cpu_reference_baseline(path, rays_rank if mode == "frames" else int(rays_step), sample_f)
             if cb is not None:
                 out["cpu_baseline"] = cb
                 # like for like: the reference's frame is the scene file's own view
                 out["config"]["scene_view_ms_per_frame"] = view0_ms
                 out["config"]["speedup_vs_cpu_reference_ms_per_frame"] = cb["ms_per_frame"] / (view0_ms or ms_per_step)
+                # (no published figure exists for this metric on this hardware: the baseline is the reference
+                # itself, timed in this run on this box's host cores, frame time against frame time)
+                out["vs_baseline"] = cb["ms_per_frame"] / (view0_ms or ms_per_step)
+                out["config"]["vs_baseline_is"] = "cpu_baseline.ms_per_frame / scene_view_ms_per_frame (same view, same run, same box)"
                 if parity is not None and ref_img is not None and ref_img.shape == parity_rgb.shape:
                     parity["vs_reference_ppm"] = image_delta(parity_rgb, ref_img)
         if parity is not None:
@@ -780,16 +873,18 @@ def measure_static(R: Rank, args, name, mode, steps, warmup, with_cpu, pipelined
     return out
 
 
-def measure_sequence(R: Rank, args, name, steps, warmup, whole, inflight=1):
+def measure_sequence(R: Rank, args, name, steps, warmup, whole, inflight=1, parity_frames=0):
     """camera_around_david: rank r renders frames r, r + N, ... of the 360-frame sequence through
     the animation pipeline (geometry loaded and uploaded once per rank; per frame the scene
     file is re-read for camera and lights only).  whole: every frame of the sequence once
     (steps is ignored); otherwise `steps` frames per rank after `warmup` earlier ones.
-    inflight > 1: that many frames of a rank are in flight at once, each on a pipeline of its own
-    (host scene, device scene, image buffer, host thread): while one frame's last, thin ray
-    generations drain -- a few long rays in an otherwise idle GPU -- the next frame's full
-    generations run beside them."""
-    import threading
+    inflight > 1: that many frames of a rank are in flight at once on the rank's ONE device scene,
+    each in a frame context of its own (rtx_frame_create; submitted with rtx_render_async, collected
+    when the context's turn comes round again): while one frame's last, thin ray generations drain --
+    a few long rays in an otherwise idle GPU -- the next frames' full generations run beside them.
+    parity_frames > 0 (rank 0): that many frames spread over the sequence are rendered once more,
+    untimed, and compared with the CPU restatement of the reference (hit records and picture)."""
+    import numpy as np
     import raytracer_amd as rt
     from raytracer_amd import distributed as D
     world, rank = R.world, R.rank
@@ -806,51 +901,46 @@ def measure_sequence(R: Rank, args, name, steps, warmup, whole, inflight=1):
     descr = files[needed[0]][1]
     R.note(f"sequence {name}: loading the geometry once per rank")
     t0 = time.time()
-    pipes = []
-    for _ in range(max(1, inflight)):
-        hs = rt.HostScene(files[mine[0]][0])
-        ds = rt.DeviceScene(hs.desc, R.local_rank)
-        cam, _ = hs.camera(0)
-        if inflight > 1:
-            # as the command line's animation pipeline runs: no event pairs round the generations
-            # (rtx_stats.trace_ms stays 0; they cost an 800x800 frame 3-4 %)
-            ds.set_generation_timing(False)
-        pipes.append((hs, ds, R.pinned(cam.height * cam.width * 3).reshape(cam.height, cam.width, 3)))
+    k_fl = max(1, inflight)
+    hs = rt.HostScene(files[mine[0]][0])
+    ds = rt.DeviceScene(hs.desc, R.local_rank)
+    cam, _ = hs.camera(0)
+    if k_fl > 1:
+        # as the command line's animation pipeline runs: no event pairs round the generations
+        # (rtx_stats.trace_ms stays 0; they cost an 800x800 frame 3-4 %)
+        ds.set_generation_timing(False)
+    slots = [(ds.frame(), R.pinned(cam.height * cam.width * 3).reshape(cam.height, cam.width, 3)) for _ in range(k_fl)]
     t_setup = time.time() - t0
-    hs, ds, _ = pipes[0]
+    lights_now = [None]
 
-    def render(f, pipe=0):
-        phs, pds, pframe = pipes[pipe]
-        if not phs.load_next(files[f][0]):
+    def next_frame(f):
+        """The host side of a frame: its file re-read for camera and lights (geometry kept)."""
+        if not hs.load_next(files[f][0]):
             raise SystemExit(f"frame {f}: the geometry was not kept")
-        pds.update_lights(phs.lights())
-        c, _ = phs.camera(0)
-        return pds.render(c, out=pframe)[2]
+        lights = hs.lights()
+        key = b"".join(bytes(l) for l in lights)
+        if key != lights_now[0]:                       # (a new version of the lights only when they changed)
+            ds.update_lights(lights)
+            lights_now[0] = key
+        return hs.camera(0)[0]
 
     def render_all(frames):
-        """frames dealt round-robin to the pipelines, one host thread each -> list of rtx_stats"""
-        if len(pipes) == 1:
-            return [render(f) for f in frames]
-        results, errors = [[] for _ in pipes], []
-
-        def work(p):
-            try:
-                results[p] = [render(f, p) for f in frames[p::len(pipes)]]
-            except BaseException as e:      # noqa: BLE001 - reported by the caller's thread
-                errors.append(e)
-        threads = [threading.Thread(target=work, args=(p,)) for p in range(len(pipes))]
-        for t in threads:
-            t.start()
-        for t in threads:
-            t.join()
-        if errors:
-            raise errors[0]
-        return [s for r in results for s in r]
+        """-> list of rtx_stats, in frame order"""
+        stats, q = [], []
+        for i, f in enumerate(frames):
+            fr, buf = slots[i % k_fl]
+            if len(q) == k_fl:
+                stats.append(q.pop(0).wait()[2])
+            fr.submit(next_frame(f), out=buf)
+            q.append(fr)
+        for fr in q:
+            stats.append(fr.wait()[2])
+        return stats
 
     # rays need no device counters (rtx_stats fills them from the queue fill levels), so the
     # timed frames themselves give the count
-    R.note(f"sequence: timed frames ({len(pipes)} in flight)")
-    render_all(warm * len(pipes))
+    R.note(f"sequence: timed frames ({k_fl} in flight)")
+    render_all(warm * k_fl)
     R.barrier()
     t0 = time.perf_counter()
     stats = render_all(mine)
@@ -858,13 +948,34 @@ def measure_sequence(R: Rank, args, name, steps, warmup, whole, inflight=1):
     elapsed = R.reduce([time.perf_counter() - t0], "max")[0]
     rays_mine = sum(int(s["rays"]) for s in stats)
     rays_all, frames_all = R.reduce([rays_mine, len(mine)])
+    parity = None
+    if parity_frames > 0 and rank == 0:
+        R.note(f"sequence: {parity_frames} frames against the CPU restatement")
+        checked, worst_same, worst_delta, bad_hits = [], 1.0, 0, 0
+        for k in range(parity_frames):
+            f = needed[(k * len(needed)) // parity_frames]
+            c = next_frame(f)
+            rgb, hits, _ = ds.render(c, want_hits=True)
+            _, o_rgb, o_hits, _ = oracle_frame(hs.desc, c, R.host_threads, want_hits=True)
+            if o_rgb is None:
+                checked = None
+                break
+            d = image_delta(rgb, o_rgb)
+            worst_same, worst_delta = min(worst_same, d["identical"]), max(worst_delta, d["max_delta"])
+            bad_hits += hit_mismatches(hits, o_hits)
+            checked.append(f)
+        if checked:
+            parity = {"frames_checked": checked, "vs_oracle": {"identical_min": worst_same, "max_delta": worst_delta,
+                                                                "hit_mismatches": bad_hits,
+                                                                "pixels_per_frame": int(cam.width * cam.height)}}
     out = None
     if rank == 0:
         per_rank = max(len(D.shard_frames(n_seq, r, world)) for r in range(world)) if whole else steps
         out = {"workload": name, "description": descr,
                "sharding": "whole frames: frame f of the sequence on rank f mod N, no collective; geometry parsed, built "
                            "and uploaded once per rank, camera and lights re-read per frame",
-               "frames": int(frames_all), "frames_per_rank": per_rank, "frames_in_flight_per_gpu": len(pipes),
+               "frames": int(frames_all), "frames_per_rank": per_rank, "frames_in_flight_per_gpu": k_fl,
+               "device_scenes_per_gpu": 1,
                "generation_timing": inflight <= 1, "wall_s": elapsed,
                "frames_per_s": frames_all / elapsed, "ms_per_frame_per_gpu": elapsed / per_rank * 1e3,
                "Mrays_per_s": rays_all / elapsed / 1e6, "rays": int(rays_all), "resolution": [cam.width, cam.height],
@@ -872,9 +983,12 @@ def measure_sequence(R: Rank, args, name, steps, warmup, whole, inflight=1):
                "trace_ms_per_frame": sum(s["trace_ms"] for s in stats) / max(len(stats), 1),
                "trace_launches_per_frame": sum(s["trace_launches"] for s in stats) / max(len(stats), 1),
                "n_gpus": world}
-    for phs, pds, _ in pipes:
-        pds.close()
-        phs.close()
+        if parity is not None:
+            out["parity_sampled"] = parity
+    for fr, _ in slots:
+        fr.close()
+    ds.close()
+    hs.close()
     return out
 
 
@@ -883,7 +997,8 @@ def run_rank(args) -> int:
     world = R.world
     extras = (not args.no_extras and args.workload == "dragon_metal" and args.mode == "frames" and not args.consistent)
     if is_sequence(args.workload):
-        seq = measure_sequence(R, args, args.workload, args.steps, args.warmup, whole=False, inflight=args.inflight)
+        seq = measure_sequence(R, args, args.workload, args.steps, args.warmup, whole=False, inflight=args.inflight,
+                               parity_frames=0 if args.no_cpu_baseline else 6)
         out = None
         if R.rank == 0:
             out = {"metric": "Mrays/s (ms/frame in ms_per_step)", "value": seq["Mrays_per_s"], "unit": "Mrays/s",
@@ -898,21 +1013,28 @@ def run_rank(args) -> int:
                              with_cpu=(world == 1 and not args.no_cpu_baseline), pipelined=extras or args.pipelined)
     if extras:
         # the two other shardings of the path, measured after the main one and reported beside it
-        seq = measure_sequence(R, args, "camera_around_david", 0, 0, whole=True)
+        seq = measure_sequence(R, args, "camera_around_david", 0, 0, whole=True, parity_frames=12)
         seq2 = measure_sequence(R, args, "camera_around_david", 0, 0, whole=True, inflight=3)
-        tiles = measure_static(R, args, "grass_desert", "tiles", 5, 1, with_cpu=False)
+        # the metric's second scene, with its own roofline, CPU baseline and parity (N = 1: the reference on a
+        # 1/7 view, ~15 s of wall)
+        tiles = measure_static(R, args, "grass_desert", "tiles", 5, 1, with_cpu=(world == 1 and not args.no_cpu_baseline))
         if R.rank == 0:
             out["sequence"] = seq
-            out["sequence"]["frames_in_flight"] = {k: seq2[k] for k in ("frames_in_flight_per_gpu", "generation_timing", "wall_s", "frames_per_s",
-                                                                         "ms_per_frame_per_gpu", "Mrays_per_s")}
+            out["sequence"]["frames_in_flight"] = {k: seq2[k] for k in ("frames_in_flight_per_gpu", "device_scenes_per_gpu", "generation_timing",
+                                                                         "wall_s", "frames_per_s", "ms_per_frame_per_gpu", "Mrays_per_s")}
             out["tiled_frame"] = {k: tiles[k] for k in ("value", "unit", "ms_per_step", "n_gpus", "steps", "scaling")}
             out["tiled_frame"].update({"workload": "grass_desert", "sharding": tiles["config"]["sharding"],
                                        "resolution": tiles["config"]["resolution"],
                                        "assembled_frame_identical_to_whole_frame": tiles["config"]["assembled_frame_identical_to_whole_frame"],
                                        "rays_per_frame": tiles["config"]["rays_per_step"],
                                        "trace_ms_per_frame_rank0": tiles["roofline"]["trace_ms_per_frame"],
-                                       "l2": tiles["roofline"]["l2"],
-                                       "device_bytes_per_frame_rank0": tiles["roofline"]["device_bytes_per_frame"]})
+                                       "device_bytes_per_frame_rank0": tiles["roofline"]["device_bytes_per_frame"],
+                                       "roofline": tiles["roofline"]})
+            for k in ("cpu_baseline", "parity", "multi_gpu", "vs_baseline"):
+                if tiles.get(k) is not None:
+                    out["tiled_frame"][k] = tiles[k]
+            if tiles["config"].get("speedup_vs_cpu_reference_ms_per_frame") is not None:
+                out["tiled_frame"]["speedup_vs_cpu_reference_ms_per_frame"] = tiles["config"]["speedup_vs_cpu_reference_ms_per_frame"]
     if R.rank == 0:
         print(json.dumps(out), flush=True)
     R.close()
@@ -941,9 +1063,12 @@ def parse_args(argv=None):
                     help="frames in flight per GPU: for camera_around_david as the main workload (default 1), and for --pipelined")
     ap.add_argument("--pipelined", action="store_true",
                     help="also measure the workload with several frames in flight per GPU (--inflight, at least 2; reported as frames_in_flight)")
+    ap.add_argument("--multi-check", action="store_true",
+                    help="report the multi_gpu self-check object at N = 1 too")
     ap.add_argument("--selftest-ranks", action="store_true",
                     help="check the rank launch path only: rendezvous over gloo, no GPU work")
     ap.add_argument("--selftest-fail-rank", type=int, default=-1, help=argparse.SUPPRESS)
+    ap.add_argument("--selftest-differ-rank", type=int, default=-1, help=argparse.SUPPRESS)
     return ap.parse_args(argv)
 
 

@@ -318,6 +318,11 @@ int rtx_scene_set_generation_timing(rtx_scene* scene, int32_t enable);
 /* Cap, in bytes, of the two ray queues together (default 32 GiB). */
 int rtx_scene_set_queue_limit(rtx_scene* scene, int64_t bytes);
 
+/* Bytes of the records the traversal reads -- collapsed BVH nodes, triangles, object records -- in
+ * device memory: the working set of the closest-hit kernel (a measurement aid; no counterpart in
+ * the reference). */
+int64_t rtx_scene_record_bytes(const rtx_scene* scene);
+
 /* Development switches, for tests and measurements (no counterpart in the reference); every one
  * leaves pictures and hit records unchanged.  A scene starts with the switches named in the
  * process environment when the process creates its first scene (RTX_AMD_NO_SEARCH=1 ... for the

@@ -173,6 +173,10 @@ class DeviceScene:
     def set_queue_limit(self, nbytes: int):
         self._lib.rtx_scene_set_queue_limit(self._h, int(nbytes))
 
+    def record_bytes(self) -> int:
+        """Bytes of the traversal's records (nodes, triangles, object records) on the device."""
+        return int(self._lib.rtx_scene_record_bytes(self._h))
+
     def set_debug(self, flags: int):
         """Development switches (``_abi.DEBUG_*``; rtx_scene_set_debug): same pictures, other paths."""
         if self._lib.rtx_scene_set_debug(self._h, int(flags)) != 0:

@@ -114,7 +114,7 @@ HIT_DTYPE = [("kind", "<i4"), ("container", "<i4"), ("face", "<i4"), ("src", "<i
 AMD_SYMBOLS = ["rtx_build_bvh", "rtx_scene_create", "rtx_scene_update_lights", "rtx_render",
                "rtx_render_noalloc", "rtx_noalloc_scratch_bytes",
                "rtx_render_output_bytes", "rtx_unpack_tiles", "rtx_assemble_tiles", "rtx_scene_set_counters", "rtx_scene_set_consistent", "rtx_scene_set_generation_timing",
-               "rtx_scene_set_queue_limit", "rtx_scene_set_debug", "rtx_scene_destroy", "rtx_last_error",
+               "rtx_scene_set_queue_limit", "rtx_scene_set_debug", "rtx_scene_record_bytes", "rtx_scene_destroy", "rtx_last_error",
                "rtx_device_count", "rtx_frame_create", "rtx_render_async", "rtx_frame_wait", "rtx_frame_destroy"]
 
 # rtx_scene_set_debug switches (include/rtx_amd.h)
@@ -191,6 +191,8 @@ def load_amd_lib():
     lib.rtx_scene_set_generation_timing.restype = C.c_int
     lib.rtx_scene_set_queue_limit.argtypes = [C.c_void_p, C.c_int64]
     lib.rtx_scene_set_queue_limit.restype = C.c_int
+    lib.rtx_scene_record_bytes.argtypes = [C.c_void_p]
+    lib.rtx_scene_record_bytes.restype = C.c_int64
     lib.rtx_scene_set_debug.argtypes = [C.c_void_p, C.c_uint32]
     lib.rtx_scene_set_debug.restype = C.c_int
     lib.rtx_frame_create.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]

@@ -1463,6 +1463,10 @@ int rtx_scene_set_queue_limit(rtx_scene* sc, int64_t bytes) {
     return RTX_OK;
 }
 
+int64_t rtx_scene_record_bytes(const rtx_scene* sc) {
+    return sc ? (int64_t)sc->blas.bytes : -1;
+}
+
 int rtx_scene_set_debug(rtx_scene* sc, uint32_t flags) {
     if (!sc) return fail(RTX_EINVAL, "null scene");
     if (flags & ~(uint32_t)RTX_DEBUG_ALL) return fail(RTX_EINVAL, "unknown debug flag");

@@ -28,6 +28,20 @@ def test_bench_starts_its_own_ranks(n):
     assert len(lines) == 1, r.stdout                       # rank 0's line only
     j = json.loads(lines[0])
     assert j["n_gpus"] == n and j["rank_sum"] == n * (n + 1) / 2
+    # the self-checks an N > 1 line carries (here over gloo, on stand-in data)
+    m = j["multi_gpu"]
+    assert m["backend"] == "gloo" and m["ranks_seen"] == n
+    assert m["ms_per_step_per_rank"] == [1.0 + r for r in range(n)]
+    assert m["ms_per_step_min"] == 1.0 and m["ms_per_step_max"] == float(n)
+    assert m["frames_identical_across_ranks"] is True and len(set(m["frame_hashes"])) == 1 and len(m["frame_hashes"]) == n
+
+
+def test_a_rank_with_another_picture_is_noticed():
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "3", "--selftest-ranks", "--selftest-differ-rank", "2"], env=_env(),
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    m = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])["multi_gpu"]
+    assert m["frames_identical_across_ranks"] is False and len(set(m["frame_hashes"])) == 2
 
 
 def test_a_failing_rank_fails_the_run():

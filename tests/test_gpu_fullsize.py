@@ -145,3 +145,62 @@ def test_full_frame_properties(workloads, name, tile):
             rt.unpack_tiles(packed, cam.width, cam.height, tw, th, rank, world, frame)
         same, mx = ck.image_diff(frame, full)
         assert np.array_equal(frame, full), f"{name}: tiles x{world}: {same:.6f} identical, max delta {mx}"
+
+
+def test_grass_desert_search_equals_replay_at_4k(workloads):
+    """The default path of the 4K frame the benchmark times -- 10 000 instances searched nearest
+    first with verification -- against the index-order replay of the reference's loop
+    (utils.cpp:756-790) it stands in for: every hit record and every byte of the picture."""
+    from raytracer_amd import _abi
+    hs, ds = workloads("grass_desert")
+    cam, _ = hs.camera(0)
+    assert (cam.width, cam.height) == (3840, 2160) and hs.desc.contents.n_instances == 10_000
+    ds.set_debug(0)
+    rgb, hits, st = ds.render(cam, want_hits=True)
+    ds.set_debug(_abi.DEBUG_NO_SEARCH)
+    try:
+        r_rgb, r_hits, r_st = ds.render(cam, want_hits=True)
+    finally:
+        ds.set_debug(0)
+    assert st["instance_path"] == 1 and r_st["instance_path"] == 0
+    assert st["rays"] == r_st["rays"]
+    assert np.array_equal(hits, r_hits), f"{int((hits != r_hits).sum())} hit records differ"
+    assert np.array_equal(rgb, r_rgb)
+
+
+def test_camera_around_david_sequence_sample(tmp_path):
+    """Twelve frames spread over the 360-frame sequence the benchmark times, each through the
+    animation pipeline (rtx_host_load_next keeps the geometry, lights updated, runner.py:105-141
+    renders them one process each) at the full 800x800, against the oracle: hit records exact,
+    picture to the bar; three of them in flight at a time on one device scene."""
+    import os
+    threads = min(16, os.cpu_count() or 1)
+    frames = [30 * k + 7 for k in range(12)]
+    files = {f: bench.make_workload("camera_around_david", bench.scene_cache_dir(), f)[0] for f in frames}
+    hs = rt.HostScene(files[frames[0]])
+    ds = rt.DeviceScene(hs.desc, 0)
+    slots = [ds.frame() for _ in range(3)]
+    cams, got, q = {}, {}, []
+    for i, f in enumerate(frames):
+        fr = slots[i % 3]
+        if len(q) == 3:
+            g, old = q.pop(0)
+            got[g] = old.wait()
+        if i > 0:
+            assert hs.load_next(files[f]), "geometry kept from frame to frame"
+            ds.update_lights(hs.lights())
+        cams[f], _ = hs.camera(0)
+        assert (cams[f].width, cams[f].height) == (800, 800)
+        fr.submit(cams[f], want_hits=True)
+        q.append((f, fr))
+    for g, fr in q:
+        got[g] = fr.wait()
+    assert len({bytes(cams[f].position) for f in frames}) == len(frames)      # twelve different views
+    for f in frames:
+        rgb, hits, st = got[f]
+        o_rgb, o_hits, o_ctr, _ = ck.oracle_render(hs.desc, cams[f], nthreads=threads)
+        assert len(ck.compare_hits(hits, o_hits, allow_src_unknown=False)) == 0, f
+        same, mx = ck.image_diff(rgb, o_rgb)
+        assert mx <= MAX_DELTA and same >= MIN_SAME, (f, same, mx)
+        assert st["rays"] == o_ctr["rays"]
+    ds.close(); hs.close()

@@ -55,6 +55,35 @@ def test_noalloc_matches_render_on_two_calls_in_a_row(tmp_path):
     hs1.close(); hs2.close()
 
 
+def _free_device_bytes():
+    """hipMemGetInfo of the current device, from the HIP runtime this process has loaded."""
+    hip = C.CDLL("libamdhip64.so.7")
+    free, total = C.c_size_t(0), C.c_size_t(0)
+    assert hip.hipMemGetInfo(C.byref(free), C.byref(total)) == 0
+    return free.value
+
+
+def test_noalloc_allocates_no_device_memory(tmp_path):
+    """The property the entry point exists for: on a scene that has never been rendered (no frame
+    buffers exist yet), two calls leave the device's free memory where it was -- while the same
+    frame through rtx_render, which has to allocate its queues, does not."""
+    lib = rt.amd_lib()
+    path = scenes.scene_grass(str(tmp_path), n_instances=300, res=(160, 120), name="na_free")
+    hs = rt.HostScene(path)
+    ds = rt.DeviceScene(hs.desc, 0)
+    cam, _ = hs.camera(0)
+    before = _free_device_bytes()
+    rc, out, _ = _noalloc(lib, ds, cam, cam.width, cam.height, 0, 1)
+    assert rc == 0, lib.rtx_last_error()
+    rc, out2, _ = _noalloc(lib, ds, cam, 32, 8, 1, 2)
+    assert rc == 0, lib.rtx_last_error()
+    assert _free_device_bytes() == before
+    ref, _, _ = ds.render(cam)                       # the allocating entry point, for contrast
+    assert _free_device_bytes() < before
+    assert np.array_equal(out.reshape(ref.shape), ref)
+    ds.close(); hs.close()
+
+
 def test_noalloc_rejects_what_does_not_fit(tmp_path):
     lib = rt.amd_lib()
     path = scenes.scene_tiny(str(tmp_path), res=(1024, 1024))

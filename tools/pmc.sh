@@ -15,6 +15,6 @@ for grp in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_
            "TA_TA_BUSY_sum GRBM_GUI_ACTIVE" \
            "WRITE_SIZE"; do
   i=$((i+1))
-  timeout -s KILL 120 rocprofv3 --pmc $grp --output-format csv -d $out -o p$i -- python3 $OLDPWD/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras "$@" > $out/p$i.log 2>&1 || echo "pass $i failed"
+  timeout -s KILL 120 rocprofv3 --pmc $grp --output-format csv -d $out -o p$i -- python3 $OLDPWD/bench.py --steps 12 --warmup 2 --no-cpu-baseline --no-extras "$@" > $out/p$i.log 2>&1 || echo "pass $i failed"
 done
 ls $out

@@ -14,6 +14,5 @@ timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/s
     python3 $repo/bench.py --workload $wl --steps 20 --warmup 5 --no-extras --no-cpu-baseline "$@" > $out/bench_under_rocprof.json 2> $out/stats.err || exit 1
 cp $(find $out/stats -name "*kernel_stats.csv" | head -n 1) $out/kernel_stats.csv
 $repo/tools/pmc.sh $tag --workload $wl --no-extras "$@" > $out/pmc.log 2>&1
-python3 $repo/tools/pmc_to_json.py $repo/gpurun_out/pmc_$tag $wl $out/pmc.json > $out/pmc_summary.txt 2>&1
-python3 $repo/tools/traffic.py $repo/gpurun_out/pmc_$tag $wl $out/traffic.json >> $out/pmc_summary.txt 2>&1
+python3 $repo/tools/pmc_to_json.py $repo/gpurun_out/pmc_$tag $wl $out/pmc.json "${RTX_BUILD_ID:-?}" > $out/pmc_summary.txt 2>&1
 cat $out/kernel_stats.csv | head -n 12
