@@ -335,7 +335,9 @@ enum {
     RTX_DEBUG_NO_SEARCH = 16,        /* instances always replayed in index order (utils.cpp:756-790)  */
     RTX_DEBUG_NO_WIDE_OLD = 32,      /* wave-wide traversal only in generations of <= 512 rays        */
     RTX_DEBUG_ALL_GENERATIONS = 64,  /* every ray generation launched, empty or not                   */
-    RTX_DEBUG_ALL = 127
+    RTX_DEBUG_HALF_GRID = 128,       /* the trace grid at one wave per SIMD instead of two (a measurement of how
+                                        much of the kernel's time is latency that more waves would hide)   */
+    RTX_DEBUG_ALL = 255
 };
 int rtx_scene_set_debug(rtx_scene* scene, uint32_t flags);
 

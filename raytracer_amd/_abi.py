@@ -119,7 +119,7 @@ AMD_SYMBOLS = ["rtx_build_bvh", "rtx_scene_create", "rtx_scene_update_lights", "
 
 # rtx_scene_set_debug switches (include/rtx_amd.h)
 DEBUG_NO_SCATTER, DEBUG_POISON_QUEUES, DEBUG_GEN_TIMING, DEBUG_NO_WIDE = 1, 2, 4, 8
-DEBUG_NO_SEARCH, DEBUG_NO_WIDE_OLD, DEBUG_ALL_GENERATIONS = 16, 32, 64
+DEBUG_NO_SEARCH, DEBUG_NO_WIDE_OLD, DEBUG_ALL_GENERATIONS, DEBUG_HALF_GRID = 16, 32, 64, 128
 HOST_SYMBOLS = ["rtx_host_load", "rtx_host_load_next", "rtx_host_attach_bvh", "rtx_host_desc", "rtx_host_camera_count", "rtx_host_camera",
                 "rtx_host_timings", "rtx_host_dump", "rtx_host_free", "rtx_host_write_ppm",
                 "rtx_host_write_png", "rtx_host_last_error"]

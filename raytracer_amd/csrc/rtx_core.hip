@@ -823,7 +823,7 @@ namespace {
 // Development switches (rtx_scene_set_debug).  A scene starts with the ones named in the process
 // environment when its first scene is created (RTX_AMD_NO_SCATTER, RTX_AMD_POISON_QUEUES,
 // RTX_AMD_GEN_TIMING, RTX_AMD_NO_WIDE, RTX_AMD_NO_SEARCH, RTX_AMD_NO_WIDE_OLD,
-// RTX_AMD_ALL_GENERATIONS: read once per process); nothing reads the environment per frame.
+// RTX_AMD_ALL_GENERATIONS, RTX_AMD_HALF_GRID: read once per process); nothing reads the environment per frame.
 uint32_t debug_from_environment() {
     static const uint32_t flags = [] {
         uint32_t f = 0;
@@ -834,6 +834,7 @@ uint32_t debug_from_environment() {
         if (getenv("RTX_AMD_NO_SEARCH")) f |= RTX_DEBUG_NO_SEARCH;
         if (getenv("RTX_AMD_NO_WIDE_OLD")) f |= RTX_DEBUG_NO_WIDE_OLD;
         if (getenv("RTX_AMD_ALL_GENERATIONS")) f |= RTX_DEBUG_ALL_GENERATIONS;
+        if (getenv("RTX_AMD_HALF_GRID")) f |= RTX_DEBUG_HALF_GRID;
         return f;
     }();
     return flags;
@@ -956,6 +957,7 @@ int job_prepare(rtx_frame* fr, const rtx_camera* cam, int32_t tw, int32_t th, in
     const int G = J.G;
     // One grid of resident blocks: RTX_TRACE_WAVES waves per SIMD = that many 256-thread blocks per CU.
     J.persistent_blocks = (unsigned)sc->cus * (unsigned)RTX_TRACE_WAVES;
+    if (J.debug & RTX_DEBUG_HALF_GRID) J.persistent_blocks = (unsigned)sc->cus;       // diagnostic: one wave per SIMD
     if (noalloc) J.persistent_blocks = std::min(J.persistent_blocks, RTX_NOALLOC_BLOCKS);
     // one bit per instance per lane; every ray leaves its lane's bitmap clear
     J.inst_words = rtx_bitmap_words(J.dev.n_insts) + rtx_summary_words(J.dev.n_insts);
