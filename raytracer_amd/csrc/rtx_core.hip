@@ -544,6 +544,11 @@ int build_scene(rtx_scene& sc, const rtx_scene_desc& d) {
         }
     };
     for (int i = 0; i < d.n_meshes; i++) fill_obj(objs[(size_t)i], i, F.meshes[(size_t)i].xform, F.meshes[(size_t)i].material);
+    // tiny meshes (see RTX_LDS_TINY): untransformed, one leaf of at most two triangles, among the records kept in LDS
+    for (int i = 0, used = 0; i < d.n_meshes && i < RTX_LDS_OBJS && used < RTX_LDS_TINY; i++) {
+        Obj& o = objs[(size_t)i];
+        if (!(o.flags & (OBJ_SKIP | OBJ_XF)) && o.root_count >= 1 && o.root_count <= 2) o.flags |= (++used) << 8;
+    }
     for (int i = 0; i < d.n_instances; i++)
         fill_obj(objs[(size_t)d.n_meshes + (size_t)i], insts[(size_t)i].base_mesh, insts[(size_t)i].xform, insts[(size_t)i].material);
 

@@ -73,6 +73,11 @@ struct Inst {
 // dependent lookups (instance -> mesh -> transform).  First 256 bytes: job set-up
 // (utils.cpp:418-494); second 256 bytes: what a found hit needs (utils.cpp:533-668).
 enum { OBJ_XF = 1, OBJ_BOUNDS = 2, OBJ_SKIP = 4, OBJ_SMOOTH_VN = 8, OBJ_AFFINE = 16 };   // OBJ_AFFINE: last matrix rows are (0, 0, 0, 1)
+// Bits 8-15 of Obj::flags: 0, or 1 + the LDS slot of a *tiny* mesh -- an untransformed mesh among the
+// scene's first objects whose BVH is a single leaf of one or two triangles (a ground quad).  The
+// trace kernel keeps those triangles in LDS and tests them where it would otherwise set up a
+// traversal job: the job would be one step between two service passes.
+#define RTX_LDS_TINY 4
 struct alignas(16) Obj {
     double inv[16];                              // world -> object (Object::inverseTransformation)
     double bmin[3], bmax[3];                     // world-space AABB (valid with OBJ_BOUNDS)

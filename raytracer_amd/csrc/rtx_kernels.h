@@ -480,7 +480,7 @@ enum { LS_EMPTY = 0, LS_NEED_JOB = 1, LS_JOB_DONE = 2, LS_IN_JOB = 3 };
 #define RTX_REPLAY_CAP 3             // instance candidates a lane may turn down per service visit before it yields (instance-heavy scenes)
 #endif
 #ifndef RTX_LDS_OBJS
-#define RTX_LDS_OBJS 12              // object records (512 B each) kept in LDS per block: the first so many of the scene
+#define RTX_LDS_OBJS 10              // object records (512 B each) kept in LDS per block: the first so many of the scene
 #endif
 #ifndef RTX_SCATTER0_SHIFT
 #define RTX_SCATTER0_SHIFT 6         // generation 0: whole 8x8 pixel blocks (64 items) are scattered
@@ -552,6 +552,7 @@ struct RecOut {
 // weight -- taken from the ray record together with origin and direction, in the same trip.
 struct ObjCache {
     const Obj* lds;
+    const double* tiny;   // the triangle pairs of the scene's tiny meshes (RTX_LDS_TINY slots of 256 bytes)
     int n;
     double* ctx;          // [0] light distance, [1..3] weight, [4] pixel (low word)
     RTX_DEV const Obj* at(const Scene& S, int oi) const { return oi < n ? lds + oi : S.objs + oi; }
@@ -710,6 +711,42 @@ RTX_DEV int job_next(const Scene& S, const ObjCache& oc, Lane& L, const RecOut& 
         const int root_ref = __double2loint(ob2[12]), root_count = __double2hiint(ob2[12]);
         const int flags = __double2loint(ob2[13]);
         if (flags & OBJ_SKIP) continue;
+        if ((flags >> 8) != 0) {
+            // A tiny mesh (untransformed, one leaf of one or two triangles, kept in LDS): tested here.
+            // As a traversal job it would be one step between two service passes; the tests, their
+            // order and what an accepted hit writes are the job's (root box of bvh.cpp:132, leaf
+            // triangles in order, utils.cpp:370-381 and 427-442).
+            double enter;
+            if (!box_enter(ob2 + 6, ob2 + 9, ws, enter) || !(L.t_min >= enter)) continue;
+            const double* T = oc.tiny + ((flags >> 8) - 1) * 32;
+            int won = -1;
+            double beta = 0.0, gamma = 0.0;
+            for (int k = 0; k < 2; k++) {
+                if (k >= root_count) break;
+                const double* tk = T + 16 * k;
+                if (COUNT) tl.tri_tests++;
+                if (S.cull && L.d.x * tk[10] + L.d.y * tk[11] + L.d.z * tk[12] > 0.0) continue;      // utils.cpp:322-326
+                double t, b, g;
+                if (tri_test(tk, L.o, L.d, L.t_min, S.isect_eps, t, b, g)) { L.t_min = t; won = k; beta = b; gamma = g; }
+            }
+            if (won >= 0) {
+                L.dist = L.t_min; L.hit = 1;
+                if (out.on) {
+                    const double* tk = T + 16 * won;
+                    const V3 a = mk(tk[0], tk[1], tk[2]), e1 = mk(tk[3], tk[4], tk[5]), e2 = mk(tk[6], tk[7], tk[8]);
+                    const V3 gn = mk(tk[10], tk[11], tk[12]);
+                    const V3 point = vadd(vadd(a, sscale(beta, e1)), sscale(gamma, e2));
+                    out.bary(beta, gamma, __double2loint(tk[9]), root_ref - S.tri_key0 + won);
+                    out.kind(RTX_KIND_MESH);
+                    out.geom(L.t_min, point, gn, gn);
+                    out.owner(ob->material, ob->mesh);
+                    out.src(oi);
+                }
+                // a shadow ray with an accepted hit in front of its light is decided (see below)
+                if (!COUNT && L.is_shadow && (FAST || L.t_min < light_dist)) return 0;
+            }
+            continue;
+        }
         V3 ro = L.o, rd = L.d;
         double bound = L.t_min;
         if (flags & OBJ_XF) {
@@ -2163,6 +2200,16 @@ k_trace(const Launch* __restrict__ Lp, GenCtrl* ctrl, const int gen, double* __r
     wv.ctx = (lds_double*)(size_t)(unsigned)(size_t)(lds_double*)&lds_ctx[threadIdx.x * 5];
     for (unsigned i = threadIdx.x; i < (unsigned)oc.n * (unsigned)(sizeof(Obj) / 16); i += blockDim.x)
         ((v2d*)lds_objs)[i] = ((const RTX_GLOBAL v2d*)S.objs)[i];
+    __shared__ __attribute__((aligned(16))) double lds_tiny[RTX_LDS_TINY * 32];
+    oc.tiny = lds_tiny;
+    // the tiny meshes among them: their one or two triangle records (sixteen 16-byte pieces a mesh)
+    if (threadIdx.x < (unsigned)oc.n * 16u) {
+        const RTX_GLOBAL Obj* ob = (const RTX_GLOBAL Obj*)S.objs + (threadIdx.x >> 4);
+        const int slot = (ob->flags >> 8) - 1;
+        if (slot >= 0 && slot < RTX_LDS_TINY)
+            ((v2d*)lds_tiny)[slot * 16 + (threadIdx.x & 15u)] =
+                ((const RTX_GLOBAL v2d*)(S.blas + (size_t)(unsigned)ob->root_ref * 128u))[threadIdx.x & 15u];
+    }
     __syncthreads();
 #if RTX_WAVE_TALLY
     const long long clk_begin_all = RTX_TICK();
