@@ -710,6 +710,25 @@ def measure_static(R: Rank, args, name, mode, steps, warmup, with_cpu, pipelined
         ds.set_generation_timing(True)
         piped = {"frames_in_flight_per_gpu": k_fl, "device_scenes_per_gpu": 1, "frames": k_fl * steps * world, "wall_s": el2,
                  "ms_per_frame_per_gpu": el2 / (k_fl * steps) * 1e3, "identical_to_blocking_render": same}
+    # The eight-wide float-box records (rtx_scene_set_wide_blas; off by default): the same turntable once
+    # more, reported beside the headline -- the same bytes from fewer records.
+    wide = None
+    if pipelined and mode == "frames":
+        ds.set_wide_blas(True)
+        w_first = ds.render(turntable[turntable_frame(0, rank, world, steps)])
+        if w_first[2]["wide_blas"]:
+            same = bool(np.array_equal(w_first[0], ds.render(turntable[turntable_frame(0, rank, world, steps)])[0]))
+            ds.set_wide_blas(False)
+            same = same and bool(np.array_equal(w_first[0], ds.render(turntable[turntable_frame(0, rank, world, steps)])[0]))
+            ds.set_wide_blas(True)
+            el_w, st_w, _ = timed(R, step, steps, 1)
+            wide = {"ms_per_frame": el_w / steps * 1e3, "record_fetches_per_frame": sum(s_["record_fetches"] for s_ in st_w) / steps,
+                    "trace_ms_per_frame": sum(s_["trace_ms"] for s_ in st_w) / steps,
+                    "redone_frames": int(sum(s_["wide_blas_redone"] for s_ in st_w)),
+                    "identical_to_default_path": same,
+                    "what": "rtx_scene_set_wide_blas: three levels of the reference's BVH per 256-byte record, float boxes rounded "
+                            "outward, one stack entry per record, every job's result checked against the reference's exact leaf box"}
+        ds.set_wide_blas(False)
     # mode tiles: the assembled frame against the same frame rendered whole on rank 0
     tiles_identical = None
     if mode == "tiles" and rank == 0:
@@ -849,6 +868,10 @@ def measure_static(R: Rank, args, name, mode, steps, warmup, with_cpu, pipelined
         }
         if multi is not None:
             out["multi_gpu"] = multi
+        if wide is not None:
+            wide["record_fetches_vs_default"] = wide["record_fetches_per_frame"] / max(rec_timed, 1)
+            wide["ms_per_frame_vs_default"] = wide["ms_per_frame"] / ms_per_step
+            out["wide_blas"] = wide
         if piped is not None:
             piped["Mrays_per_s"] = rays_step * piped["frames_in_flight_per_gpu"] * steps / piped["wall_s"] / 1e6
             out["frames_in_flight"] = piped

@@ -170,6 +170,10 @@ typedef struct rtx_stats {
      * records; one per traversing lane and step of the trace kernel's main loop): always filled,
      * in every mode -- the device's own count of what it moved, whatever path the rays took. */
     uint64_t record_fetches;
+    /* rtx_scene_set_wide_blas: 1 when the frame's mesh traversal ran over the eight-wide records;
+     * wide_blas_redone: 1 when its end-of-job check failed somewhere and the frame was rendered again
+     * with the four-wide kernels (the picture returned is that second one). */
+    uint32_t wide_blas, wide_blas_redone;
 } rtx_stats;
 
 typedef struct rtx_scene rtx_scene;   /* opaque: owns the device copy of the scene */
@@ -309,6 +313,22 @@ int rtx_scene_set_counters(rtx_scene* scene, int32_t enable);
  * (rtx_scene_set_counters) cannot be combined with it: rtx_render returns RTX_EINVAL. */
 int rtx_scene_set_consistent(rtx_scene* scene, int32_t enable);
 
+/* Eight-wide BLAS; default off.  The part of the non-parity "fast traversal" row that concerns the
+ * boxes -- FP32 conservative boxes in a wide BVH -- built so that it is exact all the same: the
+ * meshes' traversal runs over 256-byte records that hold three levels of the reference's tree
+ * (bvh.cpp:187-258) with float boxes rounded outward, one stack entry per record, children in the
+ * reference's near-to-far order (bvh.cpp:139-147).  Float boxes can only let a ray into MORE leaves
+ * than the reference's FP64 test (bvh.cpp:23-56); every triangle test is the reference's
+ * (utils.cpp:327-370, strict t < t_min), and at a job's end the winning triangle's leaf is checked
+ * against the reference's exact box test -- if that fails anywhere in a frame (a hit within rounding
+ * of its leaf's faces), the frame is rendered again with the four-wide kernels
+ * (rtx_stats.wide_blas_redone).  Pictures and hit records are those of the default path; the tests
+ * assert it.  Used for scenes with at most four instances and leaves of at most 14 triangles, in the
+ * default and the consistent mode, never with work counters on (rtx_stats.wide_blas says whether a
+ * frame used it).  On an MI355X it fetches a fifth fewer records and takes the same time (DESIGN.md
+ * says why), which is why it is off by default. */
+int rtx_scene_set_wide_blas(rtx_scene* scene, int32_t enable);
+
 /* rtx_stats.trace_ms is measured with a pair of events round every ray generation's trace
  * launches (on by default).  The markers cost a frame about 50 microseconds -- 3-4 % of an
  * 800x800 frame: callers that do not read trace_ms (the animation pipeline of the command line)
@@ -337,7 +357,9 @@ enum {
     RTX_DEBUG_ALL_GENERATIONS = 64,  /* every ray generation launched, empty or not                   */
     RTX_DEBUG_HALF_GRID = 128,       /* the trace grid at one wave per SIMD instead of two (a measurement of how
                                         much of the kernel's time is latency that more waves would hide)   */
-    RTX_DEBUG_ALL = 255
+    RTX_DEBUG_FAIL_WIDE_BLAS_CHECK = 256, /* rtx_scene_set_wide_blas: behave as if the end-of-job check had failed (the
+                                        frame is then redone with the four-wide kernels: exercises that path)    */
+    RTX_DEBUG_ALL = 511
 };
 int rtx_scene_set_debug(rtx_scene* scene, uint32_t flags);
 

@@ -173,6 +173,11 @@ class DeviceScene:
     def set_queue_limit(self, nbytes: int):
         self._lib.rtx_scene_set_queue_limit(self._h, int(nbytes))
 
+    def set_wide_blas(self, enable: bool):
+        """Mesh traversal over the eight-wide float-box records (same pictures; rtx_scene_set_wide_blas)."""
+        if self._lib.rtx_scene_set_wide_blas(self._h, int(enable)) != 0:
+            raise RtxError(self._lib.rtx_last_error().decode())
+
     def record_bytes(self) -> int:
         """Bytes of the traversal's records (nodes, triangles, object records) on the device."""
         return int(self._lib.rtx_scene_record_bytes(self._h))

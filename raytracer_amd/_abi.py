@@ -101,7 +101,7 @@ class Stats(C.Structure):
                 ("wave_inner_steps", C.c_uint64), ("wave_inner_lanes", C.c_uint64),
                 ("wave_leaf_steps", C.c_uint64), ("wave_leaf_lanes", C.c_uint64),
                 ("trace_ms", C.c_double), ("trace_launches", C.c_uint32), ("instance_path", C.c_uint32),
-                ("record_fetches", C.c_uint64)]
+                ("record_fetches", C.c_uint64), ("wide_blas", C.c_uint32), ("wide_blas_redone", C.c_uint32)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -114,12 +114,12 @@ HIT_DTYPE = [("kind", "<i4"), ("container", "<i4"), ("face", "<i4"), ("src", "<i
 AMD_SYMBOLS = ["rtx_build_bvh", "rtx_scene_create", "rtx_scene_update_lights", "rtx_render",
                "rtx_render_noalloc", "rtx_noalloc_scratch_bytes",
                "rtx_render_output_bytes", "rtx_unpack_tiles", "rtx_assemble_tiles", "rtx_scene_set_counters", "rtx_scene_set_consistent", "rtx_scene_set_generation_timing",
-               "rtx_scene_set_queue_limit", "rtx_scene_set_debug", "rtx_scene_record_bytes", "rtx_scene_destroy", "rtx_last_error",
+               "rtx_scene_set_queue_limit", "rtx_scene_set_debug", "rtx_scene_record_bytes", "rtx_scene_set_wide_blas", "rtx_scene_destroy", "rtx_last_error",
                "rtx_device_count", "rtx_frame_create", "rtx_render_async", "rtx_frame_wait", "rtx_frame_destroy"]
 
 # rtx_scene_set_debug switches (include/rtx_amd.h)
 DEBUG_NO_SCATTER, DEBUG_POISON_QUEUES, DEBUG_GEN_TIMING, DEBUG_NO_WIDE = 1, 2, 4, 8
-DEBUG_NO_SEARCH, DEBUG_NO_WIDE_OLD, DEBUG_ALL_GENERATIONS, DEBUG_HALF_GRID = 16, 32, 64, 128
+DEBUG_NO_SEARCH, DEBUG_NO_WIDE_OLD, DEBUG_ALL_GENERATIONS, DEBUG_HALF_GRID, DEBUG_FAIL_WIDE_BLAS_CHECK = 16, 32, 64, 128, 256
 HOST_SYMBOLS = ["rtx_host_load", "rtx_host_load_next", "rtx_host_attach_bvh", "rtx_host_desc", "rtx_host_camera_count", "rtx_host_camera",
                 "rtx_host_timings", "rtx_host_dump", "rtx_host_free", "rtx_host_write_ppm",
                 "rtx_host_write_png", "rtx_host_last_error"]
@@ -191,6 +191,8 @@ def load_amd_lib():
     lib.rtx_scene_set_generation_timing.restype = C.c_int
     lib.rtx_scene_set_queue_limit.argtypes = [C.c_void_p, C.c_int64]
     lib.rtx_scene_set_queue_limit.restype = C.c_int
+    lib.rtx_scene_set_wide_blas.argtypes = [C.c_void_p, C.c_int32]
+    lib.rtx_scene_set_wide_blas.restype = C.c_int
     lib.rtx_scene_record_bytes.argtypes = [C.c_void_p]
     lib.rtx_scene_record_bytes.restype = C.c_int64
     lib.rtx_scene_set_debug.argtypes = [C.c_void_p, C.c_uint32]

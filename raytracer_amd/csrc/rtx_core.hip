@@ -78,9 +78,12 @@ struct rtx_scene {
     bool counters_on = false;
     bool consistent = false;
     bool generation_timing = true;  // events round every generation's trace launches (rtx_stats.trace_ms)
+    bool wide_blas = false;         // rtx_scene_set_wide_blas: mesh traversal over the eight-wide float-box records
     uint32_t debug = 0;             // RTX_DEBUG_* development switches (rtx_scene_set_debug)
     int64_t queue_limit = (int64_t)32 << 30;
-    DevBuf materials, xforms, planes, spheres, ftris, meshes, insts, blas, tri_vn;
+    DevBuf materials, xforms, planes, spheres, ftris, meshes, insts, blas, tri_vn, tri_aux;
+    bool b8_ok = false;             // the eight-wide BLAS was built for every mesh (rtx_device_types.h, Node8)
+    std::atomic<int> b8_fallbacks{0};   // frames that had to be redone with the four-wide kernels
     // Geometry is shared read-only by every frame of the scene; the lights are versioned.
     std::mutex lights_mutex;
     std::shared_ptr<LightSet> lights;                      // current version
@@ -134,12 +137,30 @@ namespace {
 struct Flat {
     std::vector<Node4> nodes;
     std::vector<Tri> tris;
+    // the eight-wide BLAS: records, triangles in its own order, per-triangle leaf boxes, per-mesh roots
+    std::vector<Node8> nodes8;
+    std::vector<Tri> tris8;
+    std::vector<TriAux> aux;            // parallel to tris8: the exact box of the reference leaf the triangle lies in
+    std::vector<std::pair<int32_t, int32_t>> root8;   // per mesh: (index into nodes8 or tris8, triangle count or 0)
+    bool b8_ok = true;                  // every leaf holds at most RTX_B8_MAX_LEAF triangles, all coordinates fit a float
     std::vector<double> tri_vn;         // RTX_VN_STRIDE doubles per triangle
     std::vector<Mesh> meshes;
     bool any_vn = false;
     int record_levels = 0;              // deepest chain of records (collapsed nodes + leaf) in any tree
     int blas_levels = 0;                // ... in any BLAS
 };
+
+// floats that bracket a double from below / from above
+float float_below(double x) {
+    float f = (float)x;
+    if ((double)f > x) f = std::nextafter(f, -INFINITY);
+    return f;
+}
+float float_above(double x) {
+    float f = (float)x;
+    if ((double)f < x) f = std::nextafter(f, INFINITY);
+    return f;
+}
 
 int push_tri(const rtx_scene_desc& d, const rtx_mesh& m, int face, Flat& F) {
     if (face < 0 || face >= m.n_faces) return fail(RTX_EINVAL, "face index outside the mesh");
@@ -176,7 +197,20 @@ int flatten_mesh(const rtx_scene_desc& d, const rtx_mesh& m, Flat& F) {
     out.has_vn = (m.smooth && m.vertex_normals) ? 1 : 0;
     if (out.has_vn) F.any_vn = true;
     if (m.n_faces < 0 || (m.n_faces > 0 && !m.faces)) return fail(RTX_EINVAL, "mesh without faces pointer");
-    if (m.n_faces == 0) { F.meshes.push_back(out); return RTX_OK; }
+    if (m.n_faces == 0) { F.meshes.push_back(out); F.root8.emplace_back(0, 0); return RTX_OK; }
+    // a leaf's triangles into the eight-wide BLAS's own triangle array (Tri::pad = index in the
+    // reference-order array), and beside each the leaf's exact box
+    auto copy_leaf8 = [&F](int32_t first, int count, const double* mn, const double* mx) {
+        TriAux a;
+        memset(&a, 0, sizeof a);
+        memcpy(a.mn, mn, 24); memcpy(a.mx, mx, 24);
+        for (int k = 0; k < count; k++) {
+            Tri t = F.tris[(size_t)first + (size_t)k];
+            t.pad = first + k;
+            F.tris8.push_back(t);
+            F.aux.push_back(a);
+        }
+    };
     if (m.n_nodes <= 0 || !m.nodes) {
         // No BVH supplied (the -b 0 mode): one leaf holding every face in face order, which is
         // the order of the reference's brute-force loop (utils.cpp:434-441).
@@ -189,6 +223,8 @@ int flatten_mesh(const rtx_scene_desc& d, const rtx_mesh& m, Flat& F) {
             for (int k = 0; k < 3; k++) box.expand(d.vertices + 3 * (size_t)m.faces[3 * (size_t)f + k]);
         }
         memcpy(out.rmin, box.mn, sizeof box.mn); memcpy(out.rmax, box.mx, sizeof box.mx);
+        if (m.n_faces <= RTX_B8_MAX_LEAF) { F.root8.emplace_back((int32_t)F.tris8.size(), m.n_faces); copy_leaf8(out.root_ref, m.n_faces, box.mn, box.mx); }
+        else { F.root8.emplace_back(0, 0); F.b8_ok = false; }
         F.meshes.push_back(out);
         return RTX_OK;
     }
@@ -206,6 +242,7 @@ int flatten_mesh(const rtx_scene_desc& d, const rtx_mesh& m, Flat& F) {
                 int rc = push_tri(d, m, m.face_indices[nd.first_face + k], F);
                 if (rc) return rc;
             }
+            if (nd.face_count > RTX_B8_MAX_LEAF) F.b8_ok = false;
         } else {
             if (nd.left < 0 || nd.left >= n || nd.right < 0 || nd.right >= n || nd.split_axis < 0 || nd.split_axis > 2)
                 return fail(RTX_EINVAL, "BVH inner node with invalid children");
@@ -263,6 +300,66 @@ int flatten_mesh(const rtx_scene_desc& d, const rtx_mesh& m, Flat& F) {
     memcpy(out.rmin, m.nodes[0].bounds_min, 24); memcpy(out.rmax, m.nodes[0].bounds_max, 24);
     if (m.nodes[0].left == -1) { out.root_ref = leaf_start[0]; out.root_count = m.nodes[0].face_count; }
     else { Collapse c{m, leaf_start, F}; out.root_ref = c.make(0); out.root_count = 0; }
+    // ---- the same tree three levels per record (Node8), breadth first so that a record's inner
+    // children are consecutive records; the triangles of its leaf children consecutive in tris8
+    if (m.nodes[0].left == -1) {
+        F.root8.emplace_back((int32_t)F.tris8.size(), m.nodes[0].face_count);
+        if (m.nodes[0].face_count <= RTX_B8_MAX_LEAF) copy_leaf8(leaf_start[0], m.nodes[0].face_count, m.nodes[0].bounds_min, m.nodes[0].bounds_max);
+    } else if (F.b8_ok) {
+        F.root8.emplace_back((int32_t)F.nodes8.size(), 0);
+        std::vector<std::pair<int, int32_t>> todo;          // (reference node, its record)
+        todo.emplace_back(0, (int32_t)F.nodes8.size());
+        F.nodes8.emplace_back();
+        for (size_t at = 0; at < todo.size(); at++) {
+            const int ref = todo[at].first;
+            const int32_t id = todo[at].second;
+            int slot_node[8];
+            for (int& x : slot_node) x = -1;
+            Node8 o;
+            memset(&o, 0, sizeof o);
+            const rtx_bvh_node& n0 = m.nodes[ref];
+            o.axes = (uint32_t)n0.split_axis;
+            const int kid[2] = {n0.left, n0.right};
+            for (int a = 0; a < 2; a++) {
+                const rtx_bvh_node& n1 = m.nodes[kid[a]];
+                if (n1.left == -1) { slot_node[4 * a] = kid[a]; continue; }
+                o.axes |= (uint32_t)n1.split_axis << (2 + 2 * a);
+                const int kid1[2] = {n1.left, n1.right};
+                for (int b = 0; b < 2; b++) {
+                    const rtx_bvh_node& n2 = m.nodes[kid1[b]];
+                    if (n2.left == -1) { slot_node[4 * a + 2 * b] = kid1[b]; continue; }
+                    o.axes |= (uint32_t)n2.split_axis << (6 + 2 * (2 * a + b));
+                    slot_node[4 * a + 2 * b] = n2.left;
+                    slot_node[4 * a + 2 * b + 1] = n2.right;
+                }
+            }
+            bool first_inner = true, first_leaf = true;
+            for (int sl = 0; sl < 8; sl++) {
+                for (int k = 0; k < 3; k++) { o.lo[k][sl] = FLT_MAX; o.hi[k][sl] = -FLT_MAX; }
+                const int c = slot_node[sl];
+                if (c < 0) continue;
+                const rtx_bvh_node& nc = m.nodes[c];
+                for (int k = 0; k < 3; k++) {
+                    if (!(std::fabs(nc.bounds_min[k]) < 1e30) || !(std::fabs(nc.bounds_max[k]) < 1e30)) F.b8_ok = false;
+                    o.lo[k][sl] = float_below(nc.bounds_min[k]); o.hi[k][sl] = float_above(nc.bounds_max[k]);
+                }
+                if (nc.left == -1) {
+                    if (first_leaf) { o.tri_base = (uint32_t)F.tris8.size(); first_leaf = false; }
+                    o.counts |= (uint32_t)std::min(nc.face_count, 15) << (4 * sl);
+                    copy_leaf8(leaf_start[(size_t)c], nc.face_count, nc.bounds_min, nc.bounds_max);
+                } else {
+                    const int32_t cid = (int32_t)F.nodes8.size();
+                    if (first_inner) { o.child_base = (uint32_t)cid; first_inner = false; }
+                    o.counts |= 15u << (4 * sl);
+                    F.nodes8.emplace_back();
+                    todo.emplace_back(c, cid);
+                }
+            }
+            F.nodes8[(size_t)id] = o;
+        }
+    } else {
+        F.root8.emplace_back(0, 0);
+    }
     F.meshes.push_back(out);
     return RTX_OK;
 }
@@ -464,7 +561,8 @@ int build_scene(rtx_scene& sc, const rtx_scene_desc& d) {
         if ((rc = flatten_mesh(d, m, F))) return rc;
     }
     if (F.tris.size() > (size_t)INT_MAX / 2) return fail(RTX_ELIMIT, "too many triangles");
-    { Tri pad_tri; memset(&pad_tri, 0, sizeof pad_tri); F.tris.push_back(pad_tri); }   // leaf steps fetch triangles in pairs
+    { Tri pad_tri; memset(&pad_tri, 0, sizeof pad_tri); F.tris.push_back(pad_tri); F.tris8.push_back(pad_tri); }   // leaf steps fetch triangles in pairs
+    { TriAux pad_aux; memset(&pad_aux, 0, sizeof pad_aux); F.aux.push_back(pad_aux); }
     // instances: effective transform (utils.cpp:418,446,476) and TLAS over their world boxes
     std::vector<Inst> insts((size_t)d.n_instances);
     std::vector<TlasItem> items;
@@ -567,16 +665,36 @@ int build_scene(rtx_scene& sc, const rtx_scene_desc& d) {
     HIP_TRY(sc.meshes.upload(F.meshes));  S.meshes = (const Mesh*)sc.meshes.p;
     HIP_TRY(sc.insts.upload(insts));      S.insts = (const Inst*)sc.insts.p;
     {
-        // (the object records share the allocation so that the traversal's record fetch reaches them)
+        // (the object records share the allocation so that the traversal's record fetch reaches them;
+        // behind them the eight-wide BLAS: its records, then its triangles in its own order)
         const size_t nb = F.nodes.size() * sizeof(Node4), tb = F.tris.size() * sizeof(Tri), ob = objs.size() * sizeof(Obj);
-        if ((nb + tb + ob) / 128 > (size_t)INT_MAX) return fail(RTX_ELIMIT, "BLAS larger than 256 GB");
-        HIP_TRY(sc.blas.ensure(std::max<size_t>(nb + tb + ob, 16)));
+        const bool b8 = F.b8_ok && F.root8.size() == (size_t)d.n_meshes;
+        const size_t n8b = b8 ? F.nodes8.size() * sizeof(Node8) : 0, t8b = b8 ? F.tris8.size() * sizeof(Tri) : 0;
+        if ((nb + tb + ob + n8b + t8b) / 128 > (size_t)INT_MAX) return fail(RTX_ELIMIT, "BLAS larger than 256 GB");
+        if (b8) {
+            // record and triangle indices -> keys
+            const uint32_t n8_key0 = (uint32_t)((nb + tb + ob) / 128), t8_key0 = (uint32_t)((nb + tb + ob + n8b) / 128);
+            S.t8_key0 = (int32_t)t8_key0;
+            for (Node8& n : F.nodes8) { n.child_base = n8_key0 + 2u * n.child_base; n.tri_base = t8_key0 + n.tri_base; }
+            for (int i = 0; i < d.n_meshes; i++) {
+                const auto& r = F.root8[(size_t)i];
+                objs[(size_t)i].root8_ref = (int32_t)(r.second > 0 ? t8_key0 + (uint32_t)r.first : n8_key0 + 2u * (uint32_t)r.first);
+            }
+            for (int i = 0; i < d.n_instances; i++)
+                if (insts[(size_t)i].base_mesh >= 0) objs[(size_t)d.n_meshes + (size_t)i].root8_ref = objs[(size_t)insts[(size_t)i].base_mesh].root8_ref;
+        }
+        HIP_TRY(sc.blas.ensure(std::max<size_t>(nb + tb + ob + n8b + t8b, 16)));
         if (nb) HIP_TRY(hipMemcpy(sc.blas.p, F.nodes.data(), nb, hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy((char*)sc.blas.p + nb, F.tris.data(), tb, hipMemcpyHostToDevice));
         if (ob) HIP_TRY(hipMemcpy((char*)sc.blas.p + nb + tb, objs.data(), ob, hipMemcpyHostToDevice));
+        if (n8b) HIP_TRY(hipMemcpy((char*)sc.blas.p + nb + tb + ob, F.nodes8.data(), n8b, hipMemcpyHostToDevice));
+        if (t8b) HIP_TRY(hipMemcpy((char*)sc.blas.p + nb + tb + ob + n8b, F.tris8.data(), t8b, hipMemcpyHostToDevice));
         S.blas = (const char*)sc.blas.p;
         S.obj_key0 = (int32_t)((nb + tb) / 128);
         S.objs = (const Obj*)(S.blas + nb + tb);
+        sc.b8_ok = b8;
+        S.tri_aux = nullptr;
+        if (b8) { HIP_TRY(sc.tri_aux.upload(F.aux)); S.tri_aux = (const TriAux*)sc.tri_aux.p; }
     }
     if (F.any_vn) { HIP_TRY(sc.tri_vn.upload(F.tri_vn)); S.tri_vn = (const double*)sc.tri_vn.p; }
     else {
@@ -778,13 +896,15 @@ struct Job {
     // the scene as it was when the frame was submitted
     Scene dev{};
     std::shared_ptr<LightSet> lights;
-    bool counters_on = false, consistent = false, timing = true;
+    bool counters_on = false, consistent = false, timing = true, wide_blas = false;
     uint32_t debug = 0;
     // progress
     uint32_t overflows = 0, trace_launches = 0, instance_path = 0;
     float kernel_ms = 0.f, trace_ms = 0.f;
     int g_first = 0;
     bool search = false, two_variants = false;
+    bool no_b8 = false;             // the eight-wide BLAS is not to be used (this render is a redo after its check failed)
+    bool b8 = false;                // this attempt runs the eight-wide BLAS's kernels
     TraceKernel trace_main = nullptr, trace_tiny = nullptr;
     std::chrono::high_resolution_clock::time_point wall0;
 };
@@ -909,7 +1029,7 @@ int job_prepare(rtx_frame* fr, const rtx_camera* cam, int32_t tw, int32_t th, in
     if (g.n_sel == 0) { nothing_to_do = true; return RTX_OK; }
     HIP_TRY(hipSetDevice(sc->device));
     // the scene's state as of now: flags, and the current version of the lights
-    J.counters_on = sc->counters_on; J.consistent = sc->consistent; J.debug = sc->debug;
+    J.counters_on = sc->counters_on; J.consistent = sc->consistent; J.debug = sc->debug; J.wide_blas = sc->wide_blas;
     J.timing = sc->generation_timing || (sc->debug & RTX_DEBUG_GEN_TIMING);
     J.dev = sc->dev;
     {
@@ -1171,8 +1291,15 @@ int job_start_attempt(rtx_frame* fr) {
     if (J.counters_on) HIP_TRY(hipMemsetAsync(M.counters, 0, (size_t)G * sizeof(Counters), fr->stream));
     // every generation's trace launches (main variant and the one for tiny generations) are
     // bracketed by events: rtx_stats.trace_ms is the sum of their durations
+    // The eight-wide BLAS (rtx_device_types.h, Node8): scenes whose instances are few enough to be taken
+    // one after the other, without a walk of the TLAS (that walk and the candidate marks work on the
+    // four-wide records).  Its drained waves hand their last jobs to the wave-wide traversal of the
+    // four-wide records, where they start over with what they have found as their bound.
+    J.b8 = J.wide_blas && sc->b8_ok && !J.no_b8 && !J.counters_on && !nest && !search && J.dev.n_insts <= RTX_LINEAR_INSTS;
     J.trace_main =
-        J.counters_on ? k_trace<true, 0, false>
+        J.b8 ? (launch.wide_old ? (J.consistent ? k_trace<false, 1, true, 0, true> : k_trace<false, 1, false, 0, true>)
+                                : (J.consistent ? k_trace<false, 0, true, 0, true> : k_trace<false, 0, false, 0, true>))
+        : J.counters_on ? k_trace<true, 0, false>
         : nest ? k_trace<false, 0, true, 1>
         : search ? k_trace<false, 0, false, 2>
         : J.consistent ? (launch.wide_old ? k_trace<false, 1, true> : k_trace<false, 0, true>)
@@ -1333,6 +1460,14 @@ int frame_wait(rtx_frame* fr, rtx_stats* stats) {
                 peak = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(peak, ((sub.counts & 0xFFFFFFFFull) + (sub.counts >> 32)) * RTX_NSUB), 0x7FFFFFF0ull);
         }
         if (limit) return fail(RTX_ELIMIT, "a traversal stack or frontier overflowed on the device: the picture would be incomplete");
+        if (J.b8 && (ctrl[0].inexact != 0 || (J.debug & RTX_DEBUG_FAIL_WIDE_BLAS_CHECK))) {
+            // a triangle was accepted in a leaf the reference's exact box test may keep the ray out of: the
+            // frame again, with the four-wide kernels (whose visited leaves are the reference's own)
+            J.no_b8 = true;
+            sc->b8_fallbacks.fetch_add(1);
+            if ((rc = job_start_attempt(fr))) return rc;
+            continue;
+        }
         if (!overflow) break;
         J.overflows++;
         if (J.noalloc) {
@@ -1389,6 +1524,7 @@ int frame_wait(rtx_frame* fr, rtx_stats* stats) {
         stats->wave_leaf_steps = ctr.leaf_steps; stats->wave_leaf_lanes = ctr.leaf_lanes;
         stats->kernel_ms = J.kernel_ms;
         stats->trace_ms = J.trace_ms; stats->trace_launches = J.trace_launches; stats->instance_path = J.instance_path;
+        stats->wide_blas = J.b8 ? 1u : 0u; stats->wide_blas_redone = J.no_b8 ? 1u : 0u;
         for (int k = 0; k <= G; k++) stats->record_fetches += ctrl[k].records;
         stats->total_ms = std::chrono::duration<double, std::milli>(std::chrono::high_resolution_clock::now() - J.wall0).count();
     }
@@ -1467,6 +1603,12 @@ int rtx_scene_set_generation_timing(rtx_scene* sc, int32_t enable) {
 int rtx_scene_set_queue_limit(rtx_scene* sc, int64_t bytes) {
     if (!sc || bytes < (int64_t)(1 << 20)) return fail(RTX_EINVAL, "bad queue limit");
     sc->queue_limit = bytes;
+    return RTX_OK;
+}
+
+int rtx_scene_set_wide_blas(rtx_scene* sc, int32_t enable) {
+    if (!sc) return fail(RTX_EINVAL, "null scene");
+    sc->wide_blas = enable != 0;
     return RTX_OK;
 }
 

@@ -54,6 +54,34 @@ struct alignas(16) Tri { double a[3], e1[3], e2[3]; int32_t face, pad; double gn
 static_assert(sizeof(Tri) == 128, "Tri must be 128 bytes");
 #define RTX_VN_STRIDE 10      // doubles per triangle in tri_vn (9 used; keeps records 16-byte aligned)
 
+// The eight-wide BLAS ("BLAS8") of the default and consistent modes' main kernels.  Three levels of
+// the reference's binary BVH in one 256-byte record; the boxes are the reference's own, stored as
+// floats rounded OUTWARD, so a box test on them can only let more through than the reference's
+// (bvh.cpp:23-56) does.  Slot s = the 3-bit path (left/right at each of the three levels) from the
+// node the record stands for; a leaf met above the third level sits in the first slot of its range.
+// The inner children of a record are consecutive records and the triangles of its leaf children are
+// consecutive in a triangle array of its own (Tri records in this order, Tri::pad = the triangle's
+// index in the reference-order array): a child is named by its slot alone, and the stack holds
+// ONE entry per record (the children still to visit), not one per child.
+// Exactness does not rest on these boxes: the kernel visits a superset of the reference's leaves in
+// the reference's own order, every triangle test is the reference's FP64 test, and at a job's end
+// the winning triangle is checked against the exact box of its reference leaf (TriAux): the
+// reference visits that leaf whenever its box test passes with a bound no smaller than the hit.
+struct alignas(16) Node8 {
+    float lo[3][8];              // pieces 0-5: min x (slots 0-7), min y, min z
+    float hi[3][8];              // pieces 6-11: max x, max y, max z
+    uint32_t child_base;         // key of the first inner child's record
+    uint32_t tri_base;           // key of the first leaf child's first triangle (fast-order triangle array)
+    uint32_t counts;             // four bits per slot: 0 empty, 1..14 triangles of a leaf, 15 inner
+    uint32_t axes;               // two bits each: split axis of the node, of its two children (left, right), of its four grandchildren
+    uint32_t pad[12];
+};
+static_assert(sizeof(Node8) == 256, "Node8 must be 256 bytes");
+#define RTX_B8_MAX_LEAF 14
+// Per triangle of the eight-wide BLAS's triangle array: the exact (FP64) box of the reference BVH leaf that holds it.
+struct alignas(16) TriAux { double mn[3], mx[3]; double pad[2]; };
+static_assert(sizeof(TriAux) == 64, "TriAux must be 64 bytes");
+
 struct Mesh {
     double rmin[3], rmax[3];     // root box (tested before anything else, bvh.cpp:132 on node 0)
     int32_t root_ref, root_count;
@@ -83,7 +111,7 @@ struct alignas(16) Obj {
     double bmin[3], bmax[3];                     // world-space AABB (valid with OBJ_BOUNDS)
     double rmin[3], rmax[3];                     // root box of the mesh's BVH (object space)
     int32_t root_ref, root_count, flags, mesh;   // mesh: index of the (base) mesh
-    int32_t material, pad0[3];
+    int32_t material, root8_ref, pad0[2];        // root8_ref: the root in the eight-wide BLAS (record key, or its triangles' key for a leaf root)
     double m[16];                                // object -> world
     double nrm[12];                              // rows 0-2 of the normal matrix
     int32_t pad1[8];
@@ -132,6 +160,8 @@ struct Scene {
     const char* blas;
     int32_t tri_key0, obj_key0;
     const double* tri_vn;     // RTX_VN_STRIDE per triangle (vertex normals of its corners) or null
+    const TriAux* tri_aux;    // per triangle of the eight-wide BLAS (key - t8_key0): exact box of its reference leaf
+    int32_t t8_key0, pad_b8;  // key of the eight-wide BLAS's first triangle
     // TLAS: Node4 records among the BLAS records (a slot with cnt == -2 is instance `ref`);
     // box of everything and key of the root record
     double tl_min[3], tl_max[3];
@@ -200,7 +230,11 @@ struct alignas(128) GenCtrl {
     SubCount sub[RTX_NSUB];
     unsigned head_trace, head_shade, overflow, limit;
     unsigned search_back[5];
-    unsigned pad[3];
+    // inexact (first control block): a job of the eight-wide BLAS ended with a triangle whose reference
+    // leaf the reference's own box test would not have let it into; the host renders the frame again
+    // with the four-wide kernels
+    unsigned inexact;
+    unsigned pad[2];
     unsigned tally[16];
     unsigned pad2[2];
     unsigned long long records;

@@ -520,6 +520,7 @@ struct Lane {
     int state;
     int age;                // traversal steps spent on the current job (with counters on: on the current ray)
     v4i top;                // top stack entry (valid while sp > 0)
+    double bound_before;    // eight-wide records: the bound that the job's best triangle was tested against
 };
 
 // Where a lane's record goes.  Shadow rays need only (hit, distance), which stay in registers.
@@ -589,7 +590,7 @@ RTX_DEV void ray_begin(const Scene& S, Lane& L, const RecOut& out, const double 
 // up: rayHitsMesh's prologue, utils.cpp:418-494 + the root test of bvh.cpp:132), the object
 // sequence is exhausted (returns 0), or the lane has turned down CAP instance candidates in
 // this call (returns 2: call again in the next service pass).
-template <bool COUNT, bool FAST, int CAP, int NEST>
+template <bool COUNT, bool FAST, int CAP, int NEST, bool B8>
 RTX_DEV int job_next(const Scene& S, const ObjCache& oc, Lane& L, const RecOut& out, unsigned* inst_bits, glob_v4i* stk, const double light_dist, Tally& tl) {
     const unsigned n_summary = rtx_summary_words(S.n_insts);
     const Slab ws = make_slab(L.o, L.d);         // world-space slab constants, once per call
@@ -694,7 +695,7 @@ RTX_DEV int job_next(const Scene& S, const ObjCache& oc, Lane& L, const RecOut& 
         {
             const v2d* p2 = (const v2d*)ob->bmin;
 #pragma unroll
-            for (int k = 0; k < 7; k++) { const v2d v = p2[k]; ob2[2 * k] = v.x; ob2[2 * k + 1] = v.y; }
+            for (int k = 0; k < (B8 ? 8 : 7); k++) { const v2d v = p2[k]; ob2[2 * k] = v.x; ob2[2 * k + 1] = v.y; }
         }
         // While that record is on its way: if this was its bitmap word's last candidate, take the next
         // word (or the next summary word) now, in the same trip, instead of in a trip of its own later.
@@ -818,7 +819,8 @@ RTX_DEV int job_next(const Scene& S, const ObjCache& oc, Lane& L, const RecOut& 
             L.orig_t_min = light_dist;
         }
         L.ro = ro; L.rd = rd; L.ix = sl.ix; L.iy = sl.iy; L.iz = sl.iz; L.par = sl.par;
-        L.cur_ref = root_ref; L.cur_cnt = root_count; L.sp = 0; L.btri = -1;
+        L.cur_ref = B8 ? __double2hiint(ob2[14]) : root_ref;        // (the same root in the eight-wide BLAS: Obj::root8_ref)
+        L.cur_cnt = root_count; L.sp = 0; L.btri = -1;
         return 1;
     }
 }
@@ -839,20 +841,49 @@ RTX_DEV int nest_resume(Lane& L) {
 // (utils.cpp:533-668), including the fields the winning triangle test wrote
 // (utils.cpp:370-381, bvh.cpp:162).  beta and gamma of the winning triangle are recomputed
 // here with the same arithmetic that accepted it (same inputs, same bits).
-template <bool FAST, int NEST>
+// A job of the eight-wide BLAS has ended at triangle L.btri, object-space distance L.t_min.  The
+// traversal visited a superset of the reference's leaves in the reference's order and accepted with
+// the reference's own test, so this is the reference's triangle unless it lies in a leaf the
+// reference's box test (bvh.cpp:23-56 at bvh.cpp:132) keeps the ray out of.  The reference enters a
+// leaf when that test passes with the bound of the moment.  This traversal's bound at the same point of
+// the visiting order is never above the reference's (it has accepted everything the reference has, and
+// possibly more), so the test on the leaf's exact box with the bound this lane held when it accepted
+// the triangle (Lane::bound_before) says "entered" only if the reference's says so too.  An accepted
+// triangle that was not the reference's to test can only have lowered the bound: whatever that kept
+// out lies at or beyond it, hence beyond the final hit, and the final hit is the one checked.  When the
+// check fails (a hit within rounding of its leaf's box faces, met through the wider float boxes), the
+// frame is flagged and the host renders it again with the four-wide kernels.
+RTX_DEV void b8_verify(const Scene& S, const Lane& L) {
+    const RTX_GLOBAL v2d* ax = (const RTX_GLOBAL v2d*)(S.tri_aux + (L.btri - S.t8_key0));
+    const v2d a = ax[0], b = ax[1], c = ax[2];
+    const double mn[3] = {a.x, a.y, b.x}, mx[3] = {b.y, c.x, c.y};
+    Slab sl;
+    sl.ox = L.ro.x; sl.oy = L.ro.y; sl.oz = L.ro.z; sl.ix = L.ix; sl.iy = L.iy; sl.iz = L.iz; sl.par = L.par;
+    double enter;
+    if (!box_enter(mn, mx, sl, enter) || !(L.bound_before >= enter))
+        __hip_atomic_store(S.limit_flag + (offsetof(GenCtrl, inexact) - offsetof(GenCtrl, limit)) / 4, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+template <bool FAST, int NEST, bool B8>
 RTX_DEV void job_finalize(const Scene& S, const ObjCache& oc, Lane& L, const RecOut& out) {
     if (L.btri < 0) {
         if (FAST) L.t_min = L.orig_t_min;         // (a transformed job ran with the object-space bound)
         return;
     }
-    const int tri = L.btri - S.tri_key0;             // triangle index (the traversal works with record keys)
     const RTX_GLOBAL Tri* Tg = (const RTX_GLOBAL Tri*)(S.blas + (size_t)(unsigned)L.btri * 128u);
+    // (a job that the wave-wide traversal finished ends at a triangle of the reference-order array, found
+    // through the exact four-wide boxes: nothing to check)
+    const bool fast_key = B8 && L.btri >= S.t8_key0;
+    if (fast_key) b8_verify(S, L);
     const Obj* ob = oc.at(S, L.obj);
     if (!out.on && !(ob->flags & OBJ_XF)) {
         // a shadow ray keeps no record: of an untransformed hit only distance and flag remain
         L.dist = L.t_min; L.hit = 1;
         return;
     }
+    // triangle index in the reference-order array (the traversal works with record keys; the
+    // eight-wide BLAS's triangles are copies in its own order that carry that index)
+    const int tri = fast_key ? Tg->pad : L.btri - S.tri_key0;
     double T[9];
 #pragma unroll
     for (int k = 0; k < 3; k++) { T[k] = Tg->a[k]; T[3 + k] = Tg->e1[k]; T[6 + k] = Tg->e2[k]; }
@@ -1094,7 +1125,7 @@ RTX_DEV int search_service(const Scene& S, const ObjCache& oc, Lane& L, const Re
         if (L.btri != L.sword) return 3 + 4 * 2;
         const double w = L.orig_t_min;
         L.orig_t_min = L.dist;                    // any bound of (w, t0] decides alike: w < it
-        job_finalize<false, 0>(S, oc, L, out);    // accepted: the record is k's, the bound its world distance
+        job_finalize<false, 0, false>(S, oc, L, out);    // accepted: the record is k's, the bound its world distance
         if (!(L.t_min == w) || L.hit == 0) return 3 + 4 * 3;
         if (L.is_shadow && L.t_min < light_dist) return 0;       // occluded whatever is overwritten next (distances only shrink)
         L.age = SP_PROBE | (n << 8);
@@ -1105,7 +1136,7 @@ RTX_DEV int search_service(const Scene& S, const ObjCache& oc, Lane& L, const Re
         if (L.btri >= 0) {
             SEARCH_TALLY(6);
             const double w = L.orig_t_min;
-            job_finalize<false, 0>(S, oc, L, out);    // found, not nearer: triangle fields overwritten, bound restored
+            job_finalize<false, 0, false>(S, oc, L, out);    // found, not nearer: triangle fields overwritten, bound restored
             if (!(L.t_min == w)) return 3 + 4 * 4;
             return 0;
         }
@@ -1312,7 +1343,7 @@ RTX_DEV V3 primary_direction(const Frame& F, int px, int py) {
 
 // Divergent per-lane part of a service pass.  `fresh`: the lane has just been handed a new ray
 // (L.slot / L.o / L.d / L.is_shadow set).
-template <bool COUNT, bool FAST, int CAP, int NEST>
+template <bool COUNT, bool FAST, int CAP, int NEST, bool B8>
 RTX_DEV void service_lane(const Launch* __restrict__ Lp, const ObjCache& oc, const int gen, double* __restrict__ accum,
                           rtx_hit_id* __restrict__ aov, Lane& L, unsigned* inst_bits, glob_v4i* stk, const bool fresh, Tally& tl) {
     const Scene& S = Lp->S;
@@ -1363,7 +1394,7 @@ RTX_DEV void service_lane(const Launch* __restrict__ Lp, const ObjCache& oc, con
             // (the search's own rays are finalised by search_service; what arrives here with NEST = 2 is
             // a mesh job or a ray handed back to the index-order replay, whose L.whi is the last summary
             // word of its candidate bitmap: no nearest-first tie-break, which would overwrite it)
-            job_finalize<FAST, NEST == 1 ? 1 : 0>(S, oc, L, out);
+            job_finalize<FAST, NEST == 1 ? 1 : 0, B8>(S, oc, L, out);
         }
         if (nested && nest == -1) nest = 2;
         L.state = LS_NEED_JOB;
@@ -1394,7 +1425,7 @@ RTX_DEV void service_lane(const Launch* __restrict__ Lp, const ObjCache& oc, con
         L.bits = 0u; L.sbits = 0u; L.sword = L.whi;
     }
     const int more = srch >= 0 ? srch : decided ? 0 : (nest == 0 || nest == 1) ? nest : nest == 2 ? nest_resume(L)
-                             : job_next<COUNT, FAST, CAP, NEST>(S, oc, L, out, inst_bits, stk, light_dist, tl);
+                             : job_next<COUNT, FAST, CAP, NEST, B8>(S, oc, L, out, inst_bits, stk, light_dist, tl);
     if (COUNT) { const long long c = clock64(); tl.sec[2] += (unsigned long long)(c - c0); tl.sec[6]++; c0 = c; }
     if (more == 1) { L.state = LS_IN_JOB; return; }
     if (more == 2) { L.state = LS_NEED_JOB; return; }          // yielded: more candidates next time
@@ -2155,6 +2186,264 @@ RTX_DEV unsigned long long traverse_steps(const Scene& S, const Wave& wv, Lane& 
     return 0ull;
 }
 
+
+// ---- the eight-wide BLAS (Node8, rtx_device_types.h) ------------------------------------------
+//
+// The same jobs as traverse_steps -- (object-space ray, bound) -> nearest triangle below the bound,
+// the first in the reference's visiting order among equals -- over records that hold three levels of
+// the reference's tree with float boxes rounded outward.  What makes the step lean:
+//   * a box test is conservative, never exact: float arithmetic with an explicit error margin.  It
+//     may let a ray into a box the reference's FP64 test keeps it out of, never the other way round.
+//   * children are visited in the reference's order (near side first at each of the three splits,
+//     from the split axes and the ray's direction signs), found by permuting the 8-bit mask of the
+//     children that passed; ONE stack entry per record holds the rest of that mask, the two base
+//     keys, the children's kinds and the least entry distance of the group (rounded down to its
+//     upper 16 bits): a pop takes the next child of the top group without touching memory, and
+//     drops a group whose least entry distance the bound has since fallen below.
+//   * no per-child entry distances, no re-check of a child at its pop: its own children (or
+//     triangles) meet the then-current bound when it is visited.
+// A superset of the reference's leaves in the reference's order, with the reference's own FP64
+// triangle test and strict `t < t_min`, ends at the reference's triangle unless a triangle was
+// accepted inside a leaf the reference would not have entered; job_finalize checks the winning
+// triangle's leaf against the reference's exact box test (see there).
+struct B8Ray { float ohx, ohy, ohz, ivx, ivy, ivz, clx, cly, clz, slack; };
+
+RTX_DEV B8Ray b8_ray(const Lane& L) {
+    B8Ray r;
+    // origin as a float and the remainder, so that (x - origin) loses nothing to the origin's rounding;
+    // an axis the reference treats as parallel (|d| < 1e-9f, bvh.cpp:36) gets no constraint here
+    r.ohx = (float)L.ro.x; r.ohy = (float)L.ro.y; r.ohz = (float)L.ro.z;
+    r.ivx = (L.par & 1) ? 0.0f : (float)L.ix; r.ivy = (L.par & 2) ? 0.0f : (float)L.iy; r.ivz = (L.par & 4) ? 0.0f : (float)L.iz;
+    r.clx = (float)(L.ro.x - (double)r.ohx) * r.ivx; r.cly = (float)(L.ro.y - (double)r.ohy) * r.ivy; r.clz = (float)(L.ro.z - (double)r.ohz) * r.ivz;
+    const float cmax = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(r.ohx * r.ivx), __builtin_fabsf(r.ohy * r.ivy)), __builtin_fabsf(r.ohz * r.ivz));
+    r.slack = cmax * 1.1368684e-13f + 1e-30f;          // 2^-43 of the largest |origin x 1/d|, and a floor
+    return r;
+}
+
+#define RTX_B8_EPS 4.7683716e-7f        // 2^-21: relative margin of a float slab distance (its error is below 2^-22)
+
+// the dword `d` of a record held as 32 doubles, as a float / as an integer
+#define B8_F(rec, d) __int_as_float(((d) & 1) ? __double2hiint((rec)[(d) >> 1]) : __double2loint((rec)[(d) >> 1]))
+#define B8_U(rec, d) ((unsigned)(((d) & 1) ? __double2hiint((rec)[(d) >> 1]) : __double2loint((rec)[(d) >> 1])))
+
+// child in slot `c` of a record with base keys (child_base, tri_base) and kinds `counts`
+RTX_DEV void b8_child(const unsigned child_base, const unsigned tri_base, const unsigned counts, const unsigned c, int& ref, int& cnt) {
+    const unsigned nib = (counts >> (4u * c)) & 15u;
+    const unsigned m15 = counts & (counts >> 1) & (counts >> 2) & (counts >> 3) & 0x11111111u;      // bit 4s: slot s is inner
+    const unsigned below = (1u << (4u * c)) - 1u;
+    const unsigned rank = (unsigned)__popc(m15 & below);
+    const unsigned leaves = (counts & ~(m15 * 15u)) & below;                                          // triangle counts of the leaf slots before c
+    const unsigned sum = ((((leaves & 0x0F0F0F0Fu) + ((leaves >> 4) & 0x0F0F0F0Fu)) * 0x01010101u) >> 24);
+    const bool inner = nib == 15u;
+    ref = (int)(inner ? child_base + 2u * rank : tri_base + sum);
+    cnt = inner ? 0 : (int)nib;
+}
+// position in the visiting order -> slot: at each of the three levels the far side comes first where the flip bit is set
+RTX_DEV unsigned b8_slot(const unsigned p, const unsigned flips) {
+    const unsigned b2 = ((p >> 2) ^ flips) & 1u;
+    const unsigned b1 = ((p >> 1) ^ (flips >> (1u + b2))) & 1u;
+    const unsigned b0 = (p ^ (flips >> (3u + 2u * b2 + b1))) & 1u;
+    return b2 << 2 | b1 << 1 | b0;
+}
+
+template <bool FAST, int WIDE>
+RTX_DEV unsigned long long traverse_steps8(const Scene& S, const Wave& wv, Lane& L, glob_v4i* __restrict__ stk,
+                             const int service_threshold, const bool refillable, const int wide_lanes, const int wide_age,
+                             unsigned& n_records, Tally& tl) {
+    const char* const blas = S.blas;
+    const bool cull = S.cull != 0;
+    const double isect_eps = S.isect_eps;
+    // (the lane's job changes only in service passes, between two calls)
+    const B8Ray R = b8_ray(L);
+
+    while (true) {
+        const bool in_job = L.state == LS_IN_JOB;
+        const bool at_leaf = in_job && L.cur_cnt > 0;
+        const unsigned long long m_job = __ballot(in_job);
+        if (m_job == 0ull) break;
+        const unsigned long long m_wait = __ballot(L.state == LS_NEED_JOB || L.state == LS_JOB_DONE ||
+                                                   (refillable && L.state == LS_EMPTY));
+        if (__popcll(m_wait) >= service_threshold) break;
+        // the generation has drained and this wave holds its last few jobs: the caller finishes them wave-wide
+        if (WIDE != 0 && !refillable && __popcll(m_job) <= wide_lanes) {
+            const unsigned long long m_old = __ballot(in_job && L.age >= wide_age);
+            if (m_old != 0ull) return m_old;
+        }
+        const bool any_par = __ballot(in_job && (L.par & RTX_PAR_AXES) != 0) != 0ull;
+
+#if RTX_WAVE_TALLY == 3
+        const long long k_f0 = RTX_TICK();
+#endif
+        double rec[32];
+        n_records += (unsigned)__popcll(m_job);
+        if (__popcll(m_job) <= RTX_SPARSE_LANES) {
+            if (in_job) {
+                const RTX_GLOBAL v2d* gp = (const RTX_GLOBAL v2d*)(blas + ((size_t)(unsigned)L.cur_ref << 7));
+#pragma unroll
+                for (int p = 0; p < 16; p++) { const v2d v = gp[p]; rec[2 * p] = v.x; rec[2 * p + 1] = v.y; }
+            }
+        } else {
+            const unsigned row = coop_fetch(wv, in_job, L.cur_ref, blas);
+            row_read<0, 16>(wv, row, rec);
+            __builtin_amdgcn_wave_barrier();
+        }
+#if RTX_WAVE_TALLY == 3
+        const long long k_f1 = RTX_TICK();
+        tl.clk_fetch += (unsigned long long)(k_f1 - k_f0);
+#endif
+
+        bool need_pop = false;
+        if (in_job) {
+            L.age++;
+            if (!at_leaf) {
+                // ---- eight children: conservative float slab tests ------------------------------
+                const unsigned child_base = B8_U(rec, 48), tri_base = B8_U(rec, 49), counts = B8_U(rec, 50), axes = B8_U(rec, 51);
+                // the bound as a float that is not below it
+                float bound = (float)L.t_min;
+                if ((double)bound < L.t_min) bound = __int_as_float(__float_as_int(bound) + 1);      // (positive)
+                unsigned H = 0u;
+                float emin = INFINITY;
+#pragma unroll
+                for (int c = 0; c < 8; c++) {
+                    const float tx0 = __builtin_fmaf(B8_F(rec, c) - R.ohx, R.ivx, -R.clx), tx1 = __builtin_fmaf(B8_F(rec, 24 + c) - R.ohx, R.ivx, -R.clx);
+                    const float ty0 = __builtin_fmaf(B8_F(rec, 8 + c) - R.ohy, R.ivy, -R.cly), ty1 = __builtin_fmaf(B8_F(rec, 32 + c) - R.ohy, R.ivy, -R.cly);
+                    const float tz0 = __builtin_fmaf(B8_F(rec, 16 + c) - R.ohz, R.ivz, -R.clz), tz1 = __builtin_fmaf(B8_F(rec, 40 + c) - R.ohz, R.ivz, -R.clz);
+                    float nx = __builtin_fminf(tx0, tx1), fx = __builtin_fmaxf(tx0, tx1);
+                    float ny = __builtin_fminf(ty0, ty1), fy = __builtin_fmaxf(ty0, ty1);
+                    float nz = __builtin_fminf(tz0, tz1), fz = __builtin_fmaxf(tz0, tz1);
+                    if (any_par) {          // (an axis without a constraint)
+                        if (L.par & 1) { nx = -INFINITY; fx = INFINITY; }
+                        if (L.par & 2) { ny = -INFINITY; fy = INFINITY; }
+                        if (L.par & 4) { nz = -INFINITY; fz = INFINITY; }
+                    }
+                    const float enter = __builtin_fmaxf(__builtin_fmaxf(nx, ny), __builtin_fmaxf(nz, 0.0f));
+                    const float exit = __builtin_fminf(__builtin_fminf(fx, fy), fz);
+                    // margins: a computed distance is within 2^-22 of itself (+ slack) of the true one
+                    const float enter_c = __builtin_fmaf(-__builtin_fabsf(enter), RTX_B8_EPS, enter) - R.slack;
+                    const float exit_c = __builtin_fmaf(__builtin_fabsf(exit), RTX_B8_EPS, exit) + R.slack;
+                    const bool hit = (exit_c >= enter_c) & (bound >= enter_c) & (((counts >> (4 * c)) & 15u) != 0u);
+                    H |= hit ? (1u << c) : 0u;
+                    emin = hit ? __builtin_fminf(emin, enter_c) : emin;
+                }
+                // ---- the reference's visiting order (bvh.cpp:139-147): bit p of Hp = the child visited p-th
+                const unsigned ff = (unsigned)L.par >> 4;                 // per axis: the far side of a split along it comes first
+                unsigned flips = (ff >> (axes & 3u)) & 1u;
+                flips |= ((ff >> ((axes >> 2) & 3u)) & 1u) << 1 | ((ff >> ((axes >> 4) & 3u)) & 1u) << 2;
+                flips |= ((ff >> ((axes >> 6) & 3u)) & 1u) << 3 | ((ff >> ((axes >> 8) & 3u)) & 1u) << 4 |
+                         ((ff >> ((axes >> 10) & 3u)) & 1u) << 5 | ((ff >> ((axes >> 12) & 3u)) & 1u) << 6;
+                unsigned Hp = H;
+                {
+                    const unsigned f2 = flips >> 3;
+                    const unsigned e0 = (f2 & 1u) | (f2 & 2u) << 1 | (f2 & 4u) << 2 | (f2 & 8u) << 3;             // pairs whose two slots swap
+                    unsigned t = ((Hp >> 1) ^ Hp) & e0;
+                    Hp ^= t | (t << 1);
+                    const unsigned e1 = ((flips & 2u) ? 0x03u : 0u) | ((flips & 4u) ? 0x30u : 0u);               // halves whose two pairs swap
+                    t = ((Hp >> 2) ^ Hp) & e1;
+                    Hp ^= t | (t << 2);
+                    Hp = (flips & 1u) ? ((Hp >> 4) | (Hp << 4)) & 0xFFu : Hp;                                       // the halves themselves
+                }
+                if (Hp == 0u) {
+                    need_pop = true;
+                } else {
+                    const unsigned p = (unsigned)__ffs((int)Hp) - 1u;
+                    Hp &= Hp - 1u;
+                    b8_child(child_base, tri_base, counts, b8_slot(p, flips), L.cur_ref, L.cur_cnt);
+                    if (Hp != 0u) {
+                        // the others: one entry for the record
+                        if (L.sp >= RTX_STACK) { *S.limit_flag = 1u; }
+                        else {
+                            if (L.sp > 0) stk[L.sp - 1] = L.top;
+                            const unsigned e16 = emin > 0.0f ? ((unsigned)__float_as_int(emin) >> 16) : 0u;     // (truncated: not above emin)
+                            L.top.x = (int)child_base; L.top.y = (int)tri_base; L.top.z = (int)counts;
+                            L.top.w = (int)(Hp | flips << 8 | e16 << 16);
+                            L.sp++;
+                        }
+                    }
+                }
+            } else {
+                // ---- leaf: its next two triangles, in leaf order (bvh.cpp:150-170) ----------------
+                const int ti = L.cur_ref;
+                const bool two = L.cur_cnt >= 2;
+                const double* td = rec;
+                const double* tq = rec + 16;
+                bool culled0 = false, culled1 = false;
+                if (cull) {                                                                   // utils.cpp:322-326
+                    culled0 = L.rd.x * td[10] + L.rd.y * td[11] + L.rd.z * td[12] > 0.0;
+                    culled1 = L.rd.x * tq[10] + L.rd.y * tq[11] + L.rd.z * tq[12] > 0.0;
+                }
+                double t, b, g2;
+                if (!culled0 && tri_test(td, L.ro, L.rd, L.t_min, isect_eps, t, b, g2)) { L.bound_before = L.t_min; L.t_min = t; L.btri = ti; }
+                if (two && !culled1 && tri_test(tq, L.ro, L.rd, L.t_min, isect_eps, t, b, g2)) { L.bound_before = L.t_min; L.t_min = t; L.btri = ti + 1; }
+                L.cur_ref += 2; L.cur_cnt -= 2;
+                need_pop = L.cur_cnt <= 0;
+                if ((L.is_shadow & 2) && L.btri >= 0 && L.t_min < L.orig_t_min) {
+                    need_pop = true; L.sp = 0;         // occluder found: the job ends here
+                }
+                if ((L.is_shadow & 4) && L.btri >= 0 && L.t_min < (double)__int_as_float(__double2hiint(wv.ctx[4]))) {
+                    need_pop = true; L.sp = 0;         // the same inside a transformed object (job_next)
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+#if RTX_WAVE_TALLY == 3
+        const long long k_p0 = RTX_TICK();
+#endif
+        if (need_pop) {
+            L.state = LS_JOB_DONE;
+            while (L.sp > 0) {
+                const unsigned w = (unsigned)L.top.w;
+                unsigned Hp = w & 0xFFu;
+                // a group whose least entry distance lies beyond the bound by now is dropped whole
+                const bool stale = L.t_min < (double)__int_as_float((int)(w & 0xFFFF0000u));
+                if (!stale) {
+                    const unsigned p = (unsigned)__ffs((int)Hp) - 1u;
+                    Hp &= Hp - 1u;
+                    b8_child((unsigned)L.top.x, (unsigned)L.top.y, (unsigned)L.top.z, b8_slot(p, (w >> 8) & 0x7Fu), L.cur_ref, L.cur_cnt);
+                    L.state = LS_IN_JOB;
+                    if (Hp != 0u) { L.top.w = (int)((w & ~0xFFu) | Hp); break; }
+                }
+                --L.sp;
+                if (L.sp > 0) L.top = stk[L.sp - 1];
+                if (!stale) break;
+            }
+        }
+#if RTX_WAVE_TALLY == 3
+        { const long long k_e = RTX_TICK(); tl.clk_pop += (unsigned long long)(k_e - k_p0); tl.clk_trav += (unsigned long long)(k_p0 - k_f1); tl.passes++; }
+#endif
+    }
+    return 0ull;
+}
+
+// The last jobs of a drained wave of the eight-wide BLAS, finished by the whole wave (wide_multi).
+// The wave-wide traversal works on the four-wide records, whose stack entries are of another kind, so
+// a job starts over at its mesh's root there -- with what it has found so far as its bound: one ulp
+// above the distance of its best triangle, so that the triangle itself and any other at exactly that
+// distance are met again and the first of them in the reference's order is the result, as always.
+RTX_DEV void wide_jobs8(const Scene& S, const Wave& wv, const ObjCache& oc, Lane& L, glob_v4i* stk, unsigned* inst_bits,
+                        unsigned long long m) {
+    WideIn in;
+    in.rox = L.ro.x; in.roy = L.ro.y; in.roz = L.ro.z; in.rdx = L.rd.x; in.rdy = L.rd.y; in.rdz = L.rd.z;
+    in.ix = L.ix; in.iy = L.iy; in.iz = L.iz; in.stop = L.orig_t_min;
+    in.t_min = (L.btri >= 0 && L.t_min < DBL_MAX) ? __longlong_as_double(__double_as_longlong(L.t_min) + 1ll) : L.t_min;
+    in.par = L.par; in.shadow = L.is_shadow; in.sp = 0; in.top = (v4i)(0);
+    in.cur_ref = 0; in.cur_cnt = 0;
+    if ((m >> wv.lane) & 1ull) {
+        const Obj* ob = oc.at(S, L.obj);
+        in.cur_ref = ob->root_ref; in.cur_cnt = ob->root_count;
+    }
+    while (m != 0ull) {
+        const WideOut out = wide_multi(S, wv, in, stk, inst_bits, m);
+        const unsigned long long sel = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(out.sel >> 32)) << 32) |
+                                       (unsigned)__builtin_amdgcn_readfirstlane((int)out.sel);
+        m &= ~sel;
+        if ((sel >> wv.lane) & 1ull) {
+            if (out.t_min < INFINITY) { L.t_min = out.t_min; L.btri = out.btri; }      // (a key of the reference-order triangle array)
+            L.sp = 0;
+            L.state = LS_JOB_DONE;
+        }
+    }
+}
+
 // WIDE = 1: main variant in which drained waves finish their jobs wave-wide (wide_multi): those that
 // have run RTX_WIDE_AGE steps once at most RTX_WIDE_LANES are left, and every job from its first step in
 // generations of at most RTX_WIDE_MAX_RAYS rays.
@@ -2164,7 +2453,7 @@ RTX_DEV unsigned long long traverse_steps(const Scene& S, const Wave& wv, Lane& 
 // WIDE = 2: launched beside a WIDE = 0 main variant, for generations of at most RTX_WIDE_MAX_RAYS
 // rays, all of whose jobs it traverses wave-wide; exactly one of the two does the work, the other
 // returns at once.
-template <bool COUNT, int WIDE, bool FAST, int NEST = 0>
+template <bool COUNT, int WIDE, bool FAST, int NEST = 0, bool B8 = false>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RTX_TRACE_WAVES, RTX_TRACE_WAVES)))
 k_trace(const Launch* __restrict__ Lp, GenCtrl* ctrl, const int gen, double* __restrict__ accum,
         rtx_hit_id* __restrict__ aov, Counters* __restrict__ counters) {
@@ -2323,7 +2612,7 @@ k_trace(const Launch* __restrict__ Lp, GenCtrl* ctrl, const int gen, double* __r
                 const long long l0 = RTX_TICK();
 #endif
                 if (fresh || L.state == LS_JOB_DONE || L.state == LS_NEED_JOB)
-                    service_lane<COUNT, FAST, (WIDE == 0 && !COUNT) ? RTX_REPLAY_CAP : 0, NEST>(Lp, oc, gen, accum, aov, L, inst_bits, stk, fresh, tl);
+                    service_lane<COUNT, FAST, (WIDE == 0 && !COUNT && !B8) ? RTX_REPLAY_CAP : 0, NEST, B8>(Lp, oc, gen, accum, aov, L, inst_bits, stk, fresh, tl);
 #if RTX_WAVE_TALLY
                 clk_lane += RTX_TICK() - l0;
 #endif
@@ -2340,12 +2629,17 @@ k_trace(const Launch* __restrict__ Lp, GenCtrl* ctrl, const int gen, double* __r
 #if RTX_WAVE_TALLY
         const long long t0 = RTX_TICK();
 #endif
-        const unsigned long long m_wide = traverse_steps<COUNT, WIDE, NEST>(S, wv, L, stk, inst_bits, service_threshold, !drained, wide_lanes, wide_age, tl, n_records);
+        unsigned long long m_wide = 0ull;
+        if (B8) m_wide = traverse_steps8<FAST, WIDE>(S, wv, L, stk, service_threshold, !drained, wide_lanes, wide_age, n_records, tl);
+        else m_wide = traverse_steps<COUNT, WIDE, NEST>(S, wv, L, stk, inst_bits, service_threshold, !drained, wide_lanes, wide_age, tl, n_records);
 #if RTX_WAVE_TALLY
         const long long w0 = RTX_TICK();
         clk_steps += w0 - t0;
 #endif
-        if (!COUNT && WIDE != 0 && m_wide != 0ull) wide_jobs(S, wv, L, stk, inst_bits, m_wide);
+        if (!COUNT && WIDE != 0 && m_wide != 0ull) {
+            if (B8) wide_jobs8(S, wv, oc, L, stk, inst_bits, m_wide);
+            else wide_jobs(S, wv, L, stk, inst_bits, m_wide);
+        }
 #if RTX_WAVE_TALLY
         if (m_wide != 0ull) { clk_wide += RTX_TICK() - w0; n_wide_jobs += (unsigned)__popcll(m_wide); }
 #endif

@@ -204,3 +204,24 @@ def test_camera_around_david_sequence_sample(tmp_path):
         assert mx <= MAX_DELTA and same >= MIN_SAME, (f, same, mx)
         assert st["rays"] == o_ctr["rays"]
     ds.close(); hs.close()
+
+
+@pytest.mark.parametrize("name", ["dragon_metal", "camera_around_david", "metal_glass_plates"])
+def test_wide_blas_at_size(workloads, name):
+    """The eight-wide float-box records (rtx_scene_set_wide_blas) on the full-size frame: the bytes and
+    hit records of the default path, from fewer records, without a redo."""
+    hs, ds = workloads(name)
+    cam, _ = hs.camera(0)
+    ds.set_wide_blas(False)
+    rgb, hits, st = ds.render(cam, want_hits=True)
+    ds.set_wide_blas(True)
+    try:
+        w_rgb, w_hits, w_st = ds.render(cam, want_hits=True)
+    finally:
+        ds.set_wide_blas(False)
+    assert w_st["wide_blas"] == 1 and w_st["wide_blas_redone"] == 0
+    assert np.array_equal(hits, w_hits), f"{int((hits != w_hits).sum())} hit records differ"
+    assert np.array_equal(rgb, w_rgb)
+    assert w_st["rays"] == st["rays"]
+    if name != "metal_glass_plates":          # (its meshes are a few triangles each: nothing to save)
+        assert w_st["record_fetches"] < 0.9 * st["record_fetches"]

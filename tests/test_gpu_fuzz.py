@@ -1,6 +1,7 @@
 """Seeded random scenes (scenes.scene_random) on the GPU: the HIP core against the CPU
 restatement in its three modes -- counters on (every test of the reference carried out), the
-default mode, and the consistent mode against its own checker."""
+default mode, and the consistent mode against its own checker -- and, where a scene qualifies, the
+default and consistent modes again over the eight-wide float-box records (rtx_scene_set_wide_blas)."""
 import os
 
 import numpy as np
@@ -33,12 +34,17 @@ def test_random_scene_matches_oracle(tmp_path, seed):
         assert mx <= 2 and same >= 0.999, (seed, counters, same, mx)
         if counters:
             assert st["rays"] == o_ctr["rays"] and st["tri_tests"] == o_ctr["tri_tests"], (seed, st, o_ctr)
+    ds.set_wide_blas(True)
+    w_rgb, w_hits, w_st = ds.render(cam, want_hits=True)
+    assert np.array_equal(w_hits, hits) and np.array_equal(w_rgb, rgb), (seed, "eight-wide records")
     ds.set_consistent(True)
     c_rgb, c_hits, _, _ = ck.oracle_render(hs.desc, cam, consistent=True)
-    rgb, hits, _ = ds.render(cam, want_hits=True)
-    assert len(ck.compare_hits(hits, c_hits, allow_src_unknown=False)) == 0, seed
-    same, mx = ck.image_diff(rgb, c_rgb)
-    assert mx <= 2 and same >= 0.999, (seed, "consistent", same, mx)
+    for wide in (False, True):
+        ds.set_wide_blas(wide)
+        rgb, hits, _ = ds.render(cam, want_hits=True)
+        assert len(ck.compare_hits(hits, c_hits, allow_src_unknown=False)) == 0, (seed, wide)
+        same, mx = ck.image_diff(rgb, c_rgb)
+        assert mx <= 2 and same >= 0.999, (seed, "consistent", wide, same, mx)
     ds.close(); hs.close()
 
 
@@ -50,11 +56,17 @@ def test_detailed_random_scene_matches_oracle(tmp_path, seed):
     hs = rt.HostScene(path, True, bool(seed & 1))
     ds = rt.DeviceScene(hs.desc, 0)
     cam, _ = hs.camera(0)
+    used_wide = 0
     for consistent in (False, True):
         ds.set_consistent(consistent)
         o_rgb, o_hits, _, _ = ck.oracle_render(hs.desc, cam, consistent=consistent)
-        rgb, hits, _ = ds.render(cam, want_hits=True)
-        assert len(ck.compare_hits(hits, o_hits, allow_src_unknown=False)) == 0, (seed, consistent)
-        same, mx = ck.image_diff(rgb, o_rgb)
-        assert mx <= 2 and same >= 0.999, (seed, consistent, same, mx)
+        for wide in (False, True):
+            ds.set_wide_blas(wide)
+            rgb, hits, st = ds.render(cam, want_hits=True)
+            used_wide += st["wide_blas"]
+            assert st["wide_blas_redone"] == 0
+            assert len(ck.compare_hits(hits, o_hits, allow_src_unknown=False)) == 0, (seed, consistent, wide)
+            same, mx = ck.image_diff(rgb, o_rgb)
+            assert mx <= 2 and same >= 0.999, (seed, consistent, wide, same, mx)
+    assert used_wide in (0, 2)          # (scenes with more than four instances keep the four-wide records)
     ds.close(); hs.close()

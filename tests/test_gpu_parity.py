@@ -188,3 +188,54 @@ def test_bad_arguments_are_rejected(unit_scenes):
     with pytest.raises(rt.RtxError):
         ds.render_tiles(cam, 0, 16, 0, 1)
     ds.close()
+
+
+# ---- the eight-wide BLAS (rtx_scene_set_wide_blas): the same bytes and hit records as the default path ----
+@pytest.mark.parametrize("name", ["tiny", "bumpy_small", "david_small", "plates_small", "prims", "marching_small"])
+def test_wide_blas_equals_default(unit_scenes, name):
+    """Mesh traversal over the eight-wide float-box records: a superset of the reference's leaves in the
+    reference's order, checked at every job's end -- hit records and picture bytes of the default path,
+    in the default and the consistent mode; with work counters on the four-wide records are used."""
+    if name not in unit_scenes:
+        pytest.skip("no such unit scene")
+    hs = rt.HostScene(unit_scenes[name])
+    ds = rt.DeviceScene(hs.desc, 0)
+    cam, _ = hs.camera(0)
+    # (scenes whose meshes are reached through transformed instances, or that have none, keep the four-wide records)
+    expect = {"tiny": 1, "david_small": 1, "bumpy_small": 1}.get(name)
+    for consistent in (False, True):
+        ds.set_consistent(consistent)
+        ds.set_wide_blas(False)
+        rgb, hits, st = ds.render(cam, want_hits=True)
+        assert st["wide_blas"] == 0
+        ds.set_wide_blas(True)
+        w_rgb, w_hits, w_st = ds.render(cam, want_hits=True)
+        # (a frame in which some ray's end-of-job check fails -- "prims": axis-parallel rays along flat boxes, where
+        # the reference's own slab test rejects what the outward-rounded float test accepts -- is rendered again)
+        assert w_st["wide_blas"] + w_st["wide_blas_redone"] <= 1
+        assert expect is None or (w_st["wide_blas"] == expect and w_st["wide_blas_redone"] == 0), (name, w_st)
+        assert np.array_equal(hits, w_hits) and np.array_equal(rgb, w_rgb), (name, consistent)
+        assert w_st["rays"] == st["rays"]
+    ds.set_consistent(False)
+    ds.set_counters(True)
+    _, _, c_st = ds.render(cam)
+    assert c_st["wide_blas"] == 0
+    ds.close(); hs.close()
+
+
+def test_wide_blas_redo_path(unit_scenes):
+    """A frame whose end-of-job check fails is rendered again with the four-wide kernels (forced here)."""
+    from raytracer_amd import _abi
+    hs = rt.HostScene(unit_scenes["tiny"])
+    ds = rt.DeviceScene(hs.desc, 0)
+    cam, _ = hs.camera(0)
+    ref, ref_hits, _ = ds.render(cam, want_hits=True)
+    ds.set_wide_blas(True)
+    ds.set_debug(_abi.DEBUG_FAIL_WIDE_BLAS_CHECK)
+    rgb, hits, st = ds.render(cam, want_hits=True)
+    assert st["wide_blas"] == 0 and st["wide_blas_redone"] == 1
+    assert np.array_equal(rgb, ref) and np.array_equal(hits, ref_hits)
+    ds.set_debug(0)
+    rgb, hits, st = ds.render(cam, want_hits=True)
+    assert st["wide_blas"] == 1 and st["wide_blas_redone"] == 0 and np.array_equal(rgb, ref)
+    ds.close(); hs.close()
