@@ -679,7 +679,7 @@ def measure_static(R: Rank, args, name, mode, steps, warmup, with_cpu, pipelined
     # rendered k_fl times in all.
     piped = None
     if pipelined and mode == "frames":
-        k_fl = args.inflight if args.inflight > 1 else 3
+        k_fl = args.inflight if args.inflight > 1 else 4          # (tools/inflight_sweep.py: 2, 4 and 6 in flight beat 3 on dragon_metal)
         ds.set_generation_timing(False)      # (as the command line's pipeline runs: no event pairs round the generations)
         slots = [(ds.frame(), R.pinned(cam.height * cam.width * 3).reshape(cam.height, cam.width, 3)) for _ in range(k_fl)]
         order = [turntable_frame(i, rank, world, steps) for i in range(steps)]
@@ -714,21 +714,24 @@ def measure_static(R: Rank, args, name, mode, steps, warmup, with_cpu, pipelined
     # more, reported beside the headline -- the same bytes from fewer records.
     wide = None
     if pipelined and mode == "frames":
+        # (its own device scene, created with the records: the timed one above holds none)
+        first_cam = turntable[turntable_frame(0, rank, world, steps)]
+        narrow_first = ds.render(first_cam)[0].copy()
+        timed_ds, ds = ds, rt.DeviceScene(hs.desc, R.local_rank, wide_blas=True)
         ds.set_wide_blas(True)
-        w_first = ds.render(turntable[turntable_frame(0, rank, world, steps)])
+        w_first = ds.render(first_cam)
         if w_first[2]["wide_blas"]:
-            same = bool(np.array_equal(w_first[0], ds.render(turntable[turntable_frame(0, rank, world, steps)])[0]))
-            ds.set_wide_blas(False)
-            same = same and bool(np.array_equal(w_first[0], ds.render(turntable[turntable_frame(0, rank, world, steps)])[0]))
-            ds.set_wide_blas(True)
+            same = bool(np.array_equal(w_first[0], narrow_first))
             el_w, st_w, _ = timed(R, step, steps, 1)
             wide = {"ms_per_frame": el_w / steps * 1e3, "record_fetches_per_frame": sum(s_["record_fetches"] for s_ in st_w) / steps,
                     "trace_ms_per_frame": sum(s_["trace_ms"] for s_ in st_w) / steps,
                     "redone_frames": int(sum(s_["wide_blas_redone"] for s_ in st_w)),
                     "identical_to_default_path": same,
                     "what": "rtx_scene_set_wide_blas: three levels of the reference's BVH per 256-byte record, float boxes rounded "
-                            "outward, one stack entry per record, every job's result checked against the reference's exact leaf box"}
-        ds.set_wide_blas(False)
+                            "outward, one stack entry per record, every job's result checked against the reference's exact leaf box",
+                    "record_bytes": ds.record_bytes(), "record_bytes_default": timed_ds.record_bytes()}
+        ds.close()
+        ds = timed_ds
     # mode tiles: the assembled frame against the same frame rendered whole on rank 0
     tiles_identical = None
     if mode == "tiles" and rank == 0:

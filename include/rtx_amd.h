@@ -114,11 +114,17 @@ typedef struct rtx_mesh {
  * base_mesh < 0 marks an instance whose base could not be resolved (skipped, utils.cpp:758). */
 typedef struct rtx_instance { int32_t base_mesh, material, xform, pad; } rtx_instance;
 
+/* rtx_scene_desc::build_flags (no counterpart in the reference).
+ * RTX_SCENE_WIDE_BLAS: also build and upload the eight-wide float-box records that
+ * rtx_scene_set_wide_blas switches the mesh traversal to (about two thirds more record memory and
+ * 64 bytes per triangle beside it). */
+enum { RTX_SCENE_WIDE_BLAS = 1 };
+
 typedef struct rtx_scene_desc {
     int32_t abi_version;                 /* RTX_ABI_VERSION */
     int32_t max_recursion_depth;
     int32_t enable_back_face_culling;    /* the -c flag (raytracer.cpp:199-207)          */
-    int32_t pad;
+    int32_t build_flags;                 /* RTX_SCENE_* below; 0 = the default device scene */
     double background[3], ambient[3];
     double shadow_ray_epsilon, intersection_test_epsilon;
     const double* vertices;        int64_t n_vertices;   /* 3 doubles each */
@@ -323,10 +329,12 @@ int rtx_scene_set_consistent(rtx_scene* scene, int32_t enable);
  * against the reference's exact box test -- if that fails anywhere in a frame (a hit within rounding
  * of its leaf's faces), the frame is rendered again with the four-wide kernels
  * (rtx_stats.wide_blas_redone).  Pictures and hit records are those of the default path; the tests
- * assert it.  Used for scenes with at most four instances and leaves of at most 14 triangles, in the
- * default and the consistent mode, never with work counters on (rtx_stats.wide_blas says whether a
- * frame used it).  On an MI355X it fetches a fifth fewer records and takes the same time (DESIGN.md
- * says why), which is why it is off by default. */
+ * assert it.  The records exist only in a scene created with RTX_SCENE_WIDE_BLAS in
+ * rtx_scene_desc::build_flags (RTX_EINVAL otherwise).  Used for scenes with at most four instances and
+ * leaves of at most 14 triangles, in the default and the consistent mode, never with work counters on
+ * (rtx_stats.wide_blas says whether a frame used it).  On an MI355X it fetches a fifth fewer records
+ * and takes the same time -- a step's time follows its instruction count, which eight float boxes
+ * do not lower against four double ones -- which is why it is off by default. */
 int rtx_scene_set_wide_blas(rtx_scene* scene, int32_t enable);
 
 /* rtx_stats.trace_ms is measured with a pair of events round every ray generation's trace

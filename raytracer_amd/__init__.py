@@ -149,9 +149,18 @@ def write_png(path: str, rgb: np.ndarray):
 class DeviceScene:
     """Device copy of a scene + render calls (reference: multiThreadedRayTracing)."""
 
-    def __init__(self, desc, device: int = 0):
+    def __init__(self, desc, device: int = 0, wide_blas: bool = False):
+        """wide_blas: also build the eight-wide float-box records (RTX_SCENE_WIDE_BLAS), which
+        set_wide_blas then switches the mesh traversal to."""
         self._lib = amd_lib()
         h = C.c_void_p()
+        if wide_blas:
+            # (a copy of the description with the build flag set; the arrays it points to are shared)
+            src = desc.contents if hasattr(desc, "contents") else desc
+            mine = _abi.SceneDesc()
+            C.memmove(C.byref(mine), C.byref(src), C.sizeof(_abi.SceneDesc))
+            mine.build_flags |= _abi.SCENE_WIDE_BLAS
+            desc = C.pointer(mine)
         rc = self._lib.rtx_scene_create(desc, device, C.byref(h))
         if rc != 0:
             raise RtxError(f"rtx_scene_create failed ({rc}): {self._lib.rtx_last_error().decode()}")

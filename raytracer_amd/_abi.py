@@ -72,7 +72,7 @@ class Instance(C.Structure):
 
 class SceneDesc(C.Structure):
     _fields_ = [("abi_version", C.c_int32), ("max_recursion_depth", C.c_int32),
-                ("enable_back_face_culling", C.c_int32), ("pad", C.c_int32),
+                ("enable_back_face_culling", C.c_int32), ("build_flags", C.c_int32),
                 ("background", c_double3), ("ambient", c_double3),
                 ("shadow_ray_epsilon", C.c_double), ("intersection_test_epsilon", C.c_double),
                 ("vertices", C.POINTER(C.c_double)), ("n_vertices", C.c_int64),
@@ -120,6 +120,7 @@ AMD_SYMBOLS = ["rtx_build_bvh", "rtx_scene_create", "rtx_scene_update_lights", "
 # rtx_scene_set_debug switches (include/rtx_amd.h)
 DEBUG_NO_SCATTER, DEBUG_POISON_QUEUES, DEBUG_GEN_TIMING, DEBUG_NO_WIDE = 1, 2, 4, 8
 DEBUG_NO_SEARCH, DEBUG_NO_WIDE_OLD, DEBUG_ALL_GENERATIONS, DEBUG_HALF_GRID, DEBUG_FAIL_WIDE_BLAS_CHECK = 16, 32, 64, 128, 256
+SCENE_WIDE_BLAS = 1          # rtx_scene_desc::build_flags
 HOST_SYMBOLS = ["rtx_host_load", "rtx_host_load_next", "rtx_host_attach_bvh", "rtx_host_desc", "rtx_host_camera_count", "rtx_host_camera",
                 "rtx_host_timings", "rtx_host_dump", "rtx_host_free", "rtx_host_write_ppm",
                 "rtx_host_write_png", "rtx_host_last_error"]

@@ -82,7 +82,8 @@ struct rtx_scene {
     uint32_t debug = 0;             // RTX_DEBUG_* development switches (rtx_scene_set_debug)
     int64_t queue_limit = (int64_t)32 << 30;
     DevBuf materials, xforms, planes, spheres, ftris, meshes, insts, blas, tri_vn, tri_aux;
-    bool b8_ok = false;             // the eight-wide BLAS was built for every mesh (rtx_device_types.h, Node8)
+    bool b8_built = false;          // the scene was created with RTX_SCENE_WIDE_BLAS
+    bool b8_ok = false;             // ... and the eight-wide BLAS could be built for every mesh (rtx_device_types.h, Node8)
     std::atomic<int> b8_fallbacks{0};   // frames that had to be redone with the four-wide kernels
     // Geometry is shared read-only by every frame of the scene; the lights are versioned.
     std::mutex lights_mutex;
@@ -198,6 +199,7 @@ int flatten_mesh(const rtx_scene_desc& d, const rtx_mesh& m, Flat& F) {
     if (out.has_vn) F.any_vn = true;
     if (m.n_faces < 0 || (m.n_faces > 0 && !m.faces)) return fail(RTX_EINVAL, "mesh without faces pointer");
     if (m.n_faces == 0) { F.meshes.push_back(out); F.root8.emplace_back(0, 0); return RTX_OK; }
+    // (F.b8_ok: the eight-wide records are wanted and, so far, possible)
     // a leaf's triangles into the eight-wide BLAS's own triangle array (Tri::pad = index in the
     // reference-order array), and beside each the leaf's exact box
     auto copy_leaf8 = [&F](int32_t first, int count, const double* mn, const double* mx) {
@@ -223,7 +225,7 @@ int flatten_mesh(const rtx_scene_desc& d, const rtx_mesh& m, Flat& F) {
             for (int k = 0; k < 3; k++) box.expand(d.vertices + 3 * (size_t)m.faces[3 * (size_t)f + k]);
         }
         memcpy(out.rmin, box.mn, sizeof box.mn); memcpy(out.rmax, box.mx, sizeof box.mx);
-        if (m.n_faces <= RTX_B8_MAX_LEAF) { F.root8.emplace_back((int32_t)F.tris8.size(), m.n_faces); copy_leaf8(out.root_ref, m.n_faces, box.mn, box.mx); }
+        if (F.b8_ok && m.n_faces <= RTX_B8_MAX_LEAF) { F.root8.emplace_back((int32_t)F.tris8.size(), m.n_faces); copy_leaf8(out.root_ref, m.n_faces, box.mn, box.mx); }
         else { F.root8.emplace_back(0, 0); F.b8_ok = false; }
         F.meshes.push_back(out);
         return RTX_OK;
@@ -302,10 +304,12 @@ int flatten_mesh(const rtx_scene_desc& d, const rtx_mesh& m, Flat& F) {
     else { Collapse c{m, leaf_start, F}; out.root_ref = c.make(0); out.root_count = 0; }
     // ---- the same tree three levels per record (Node8), breadth first so that a record's inner
     // children are consecutive records; the triangles of its leaf children consecutive in tris8
-    if (m.nodes[0].left == -1) {
+    if (!F.b8_ok) {
+        F.root8.emplace_back(0, 0);
+    } else if (m.nodes[0].left == -1) {
         F.root8.emplace_back((int32_t)F.tris8.size(), m.nodes[0].face_count);
         if (m.nodes[0].face_count <= RTX_B8_MAX_LEAF) copy_leaf8(leaf_start[0], m.nodes[0].face_count, m.nodes[0].bounds_min, m.nodes[0].bounds_max);
-    } else if (F.b8_ok) {
+    } else {
         F.root8.emplace_back((int32_t)F.nodes8.size(), 0);
         std::vector<std::pair<int, int32_t>> todo;          // (reference node, its record)
         todo.emplace_back(0, (int32_t)F.nodes8.size());
@@ -357,8 +361,6 @@ int flatten_mesh(const rtx_scene_desc& d, const rtx_mesh& m, Flat& F) {
             }
             F.nodes8[(size_t)id] = o;
         }
-    } else {
-        F.root8.emplace_back(0, 0);
     }
     F.meshes.push_back(out);
     return RTX_OK;
@@ -554,6 +556,8 @@ int build_scene(rtx_scene& sc, const rtx_scene_desc& d) {
         o.material = p.material; o.xform = p.xform;
     }
     Flat F;
+    F.b8_ok = (d.build_flags & RTX_SCENE_WIDE_BLAS) != 0;
+    sc.b8_built = F.b8_ok;
     for (int i = 0; i < d.n_meshes; i++) {
         const rtx_mesh& m = d.meshes[i];
         if ((rc = check_index(m.material, d.n_materials, true, "mesh material"))) return rc;
@@ -1608,6 +1612,8 @@ int rtx_scene_set_queue_limit(rtx_scene* sc, int64_t bytes) {
 
 int rtx_scene_set_wide_blas(rtx_scene* sc, int32_t enable) {
     if (!sc) return fail(RTX_EINVAL, "null scene");
+    if (enable && !sc->b8_built)
+        return fail(RTX_EINVAL, "rtx_scene_set_wide_blas: the scene was created without RTX_SCENE_WIDE_BLAS in rtx_scene_desc::build_flags");
     sc->wide_blas = enable != 0;
     return RTX_OK;
 }

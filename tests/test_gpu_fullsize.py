@@ -212,13 +212,13 @@ def test_wide_blas_at_size(workloads, name):
     hit records of the default path, from fewer records, without a redo."""
     hs, ds = workloads(name)
     cam, _ = hs.camera(0)
-    ds.set_wide_blas(False)
     rgb, hits, st = ds.render(cam, want_hits=True)
-    ds.set_wide_blas(True)
+    wide = rt.DeviceScene(hs.desc, 0, wide_blas=True)          # (a second device scene: the shared one holds no such records)
+    wide.set_wide_blas(True)
     try:
-        w_rgb, w_hits, w_st = ds.render(cam, want_hits=True)
+        w_rgb, w_hits, w_st = wide.render(cam, want_hits=True)
     finally:
-        ds.set_wide_blas(False)
+        wide.close()
     assert w_st["wide_blas"] == 1 and w_st["wide_blas_redone"] == 0
     assert np.array_equal(hits, w_hits), f"{int((hits != w_hits).sum())} hit records differ"
     assert np.array_equal(rgb, w_rgb)

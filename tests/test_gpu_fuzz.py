@@ -22,7 +22,7 @@ def test_random_scene_matches_oracle(tmp_path, seed):
     path = scenes.scene_random(str(tmp_path), seed)
     cull = bool(seed & 1)
     hs = rt.HostScene(path, True, cull)
-    ds = rt.DeviceScene(hs.desc, 0)
+    ds = rt.DeviceScene(hs.desc, 0, wide_blas=True)
     cam, _ = hs.camera(0)
     o_rgb, o_hits, o_ctr, _ = ck.oracle_render(hs.desc, cam)
     for counters in (True, False):
@@ -54,7 +54,7 @@ def test_detailed_random_scene_matches_oracle(tmp_path, seed):
     wave-wide finishing of drained waves and for the tiny-generation kernel."""
     path = scenes.scene_random(str(tmp_path), seed, res=(288, 208), detail=12)
     hs = rt.HostScene(path, True, bool(seed & 1))
-    ds = rt.DeviceScene(hs.desc, 0)
+    ds = rt.DeviceScene(hs.desc, 0, wide_blas=True)
     cam, _ = hs.camera(0)
     used_wide = 0
     for consistent in (False, True):

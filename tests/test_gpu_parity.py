@@ -199,7 +199,7 @@ def test_wide_blas_equals_default(unit_scenes, name):
     if name not in unit_scenes:
         pytest.skip("no such unit scene")
     hs = rt.HostScene(unit_scenes[name])
-    ds = rt.DeviceScene(hs.desc, 0)
+    ds = rt.DeviceScene(hs.desc, 0, wide_blas=True)
     cam, _ = hs.camera(0)
     # (scenes whose meshes are reached through transformed instances, or that have none, keep the four-wide records)
     expect = {"tiny": 1, "david_small": 1, "bumpy_small": 1}.get(name)
@@ -223,11 +223,25 @@ def test_wide_blas_equals_default(unit_scenes, name):
     ds.close(); hs.close()
 
 
+def test_wide_blas_needs_the_build_flag(unit_scenes):
+    hs = rt.HostScene(unit_scenes["tiny"])
+    ds = rt.DeviceScene(hs.desc, 0)
+    small = ds.record_bytes()
+    with pytest.raises(rt.RtxError, match="RTX_SCENE_WIDE_BLAS"):
+        ds.set_wide_blas(True)
+    ds.set_wide_blas(False)
+    ds.close()
+    ds = rt.DeviceScene(hs.desc, 0, wide_blas=True)
+    assert ds.record_bytes() > small
+    assert hs.desc.contents.build_flags == 0             # (the wrapper set the flag on a copy)
+    ds.close(); hs.close()
+
+
 def test_wide_blas_redo_path(unit_scenes):
     """A frame whose end-of-job check fails is rendered again with the four-wide kernels (forced here)."""
     from raytracer_amd import _abi
     hs = rt.HostScene(unit_scenes["tiny"])
-    ds = rt.DeviceScene(hs.desc, 0)
+    ds = rt.DeviceScene(hs.desc, 0, wide_blas=True)
     cam, _ = hs.camera(0)
     ref, ref_hits, _ = ds.render(cam, want_hits=True)
     ds.set_wide_blas(True)

@@ -13,7 +13,7 @@ from raytracer_amd import _abi  # noqa: E402
 name = sys.argv[1] if len(sys.argv) > 1 else "dragon_metal"
 path, _ = bench.make_workload(name, bench.scene_cache_dir())
 hs = rt.HostScene(path)
-ds = rt.DeviceScene(hs.desc, 0)
+ds = rt.DeviceScene(hs.desc, 0, wide_blas=True)
 cam, _ = hs.camera(0)
 for wide, flags, label in ((True, 0, "eight-wide"), (False, 0, "four-wide"), (True, _abi.DEBUG_NO_WIDE_OLD, "eight-wide, no wide finishing"),
                            (False, _abi.DEBUG_NO_WIDE_OLD, "four-wide, no wide finishing")):
