@@ -116,8 +116,8 @@ typedef struct rtx_instance { int32_t base_mesh, material, xform, pad; } rtx_ins
 
 /* rtx_scene_desc::build_flags (no counterpart in the reference).
  * RTX_SCENE_WIDE_BLAS: also build and upload the eight-wide float-box records that
- * rtx_scene_set_wide_blas switches the mesh traversal to (about two thirds more record memory and
- * 64 bytes per triangle beside it). */
+ * rtx_scene_set_wide_blas switches the mesh traversal to (the record memory about doubles -- the
+ * triangles are held a second time in that tree's leaf order -- plus 64 bytes per triangle). */
 enum { RTX_SCENE_WIDE_BLAS = 1 };
 
 typedef struct rtx_scene_desc {
