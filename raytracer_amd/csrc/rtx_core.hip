@@ -206,9 +206,14 @@ int flatten_mesh(const rtx_scene_desc& d, const rtx_mesh& m, Flat& F) {
         TriAux a;
         memset(&a, 0, sizeof a);
         memcpy(a.mn, mn, 24); memcpy(a.mx, mx, 24);
+        // ... and in the record's spare 24 bytes the same box as floats rounded INWARD (on an axis where the
+        // leaf is thinner than a float step the two cross; the kernel looks for that)
+        float in[6];
+        for (int k = 0; k < 3; k++) { in[k] = float_above(mn[k]); in[3 + k] = float_below(mx[k]); }
         for (int k = 0; k < count; k++) {
             Tri t = F.tris[(size_t)first + (size_t)k];
             t.pad = first + k;
+            memcpy(t.pad2, in, sizeof in);
             F.tris8.push_back(t);
             F.aux.push_back(a);
         }
@@ -1344,6 +1349,12 @@ void print_generation_timing(rtx_frame* fr) {
             const unsigned long long sum = *(const unsigned long long*)&ctrl[gen].tally[8], packed = *(const unsigned long long*)&ctrl[gen].tally[10];
             const unsigned long long mx = (packed >> 38) << 6;
             const unsigned n = ctrl[gen].tally[12];
+            if (n && RTX_WAVE_TALLY == 4) {
+                const unsigned long long* t = (const unsigned long long*)&ctrl[gen].tally[0];
+                fprintf(stderr, "[rtx] gen %d: %u waves, mean lifetime %.1f us, longest %.1f us; of all waves' lifetimes %.1f %% traversal steps, %.1f %% service passes "
+                        "(%.1f per wave, %.2f us each), %.1f %% wave-wide jobs\n", gen, n, (double)sum / n / 2400.0, (double)mx / 2400.0, 100.0 * (double)t[0] / (double)sum,
+                        100.0 * (double)t[1] / (double)sum, (double)t[3] / n, t[3] ? (double)t[1] / (double)t[3] / 2400.0 : 0.0, 100.0 * (double)t[2] / (double)sum);
+            } else
             if (n) fprintf(stderr, "[rtx] gen %d: %u waves, mean lifetime %.1f us, longest %.1f us (at 2.4 GHz; %u %% of it in %u wave-wide jobs, %u %% in traversal steps, %u %% in %u service passes): filled %.0f %%; "
                            "waves by lifetime in 150 us bins: %u %u %u %u %u %u %u %u+; after the queue ran dry: mean %.1f us, longest %.1f us\n", gen, n,
                            (double)sum / n / 2400.0, (double)mx / 2400.0, (unsigned)(packed >> 31) & 127u, (unsigned)(packed >> 9) & 255u,

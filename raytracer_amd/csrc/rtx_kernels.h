@@ -215,6 +215,7 @@ RTX_DEV unsigned lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amd
 #define RTX_GLOBAL __attribute__((address_space(1)))
 typedef __attribute__((address_space(3))) double lds_double;
 typedef double v2d __attribute__((ext_vector_type(2)));
+typedef float v2f __attribute__((ext_vector_type(2)));
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) v2d lds_v2d;
 typedef __attribute__((address_space(1))) v4i glob_v4i;
@@ -853,13 +854,22 @@ RTX_DEV int nest_resume(Lane& L) {
 // out lies at or beyond it, hence beyond the final hit, and the final hit is the one checked.  When the
 // check fails (a hit within rounding of its leaf's box faces, met through the wider float boxes), the
 // frame is flagged and the host renders it again with the four-wide kernels.
-RTX_DEV void b8_verify(const Scene& S, const Lane& L) {
-    const RTX_GLOBAL v2d* ax = (const RTX_GLOBAL v2d*)(S.tri_aux + (L.btri - S.t8_key0));
-    const v2d a = ax[0], b = ax[1], c = ax[2];
-    const double mn[3] = {a.x, a.y, b.x}, mx[3] = {b.y, c.x, c.y};
+RTX_DEV void b8_verify(const Scene& S, const Lane& L, const RTX_GLOBAL Tri* Tg) {
     Slab sl;
     sl.ox = L.ro.x; sl.oy = L.ro.y; sl.oz = L.ro.z; sl.ix = L.ix; sl.iy = L.iy; sl.iz = L.iz; sl.par = L.par;
     double enter;
+    {
+        // First the leaf's box rounded inward to floats, from the triangle's own record (the line the traversal
+        // has just had; the exact boxes are a cold array): a box inside the exact one that lets the ray in under
+        // the bound says that the exact one does (the slab arithmetic is monotone in every plane).
+        const RTX_GLOBAL v2f* ib = (const RTX_GLOBAL v2f*)Tg->pad2;
+        const v2f p = ib[0], q = ib[1], r = ib[2];
+        const double mn[3] = {(double)p.x, (double)p.y, (double)q.x}, mx[3] = {(double)q.y, (double)r.x, (double)r.y};
+        if (mn[0] <= mx[0] && mn[1] <= mx[1] && mn[2] <= mx[2] && box_enter(mn, mx, sl, enter) && L.bound_before >= enter) return;
+    }
+    const RTX_GLOBAL v2d* ax = (const RTX_GLOBAL v2d*)(S.tri_aux + (L.btri - S.t8_key0));
+    const v2d a = ax[0], b = ax[1], c = ax[2];
+    const double mn[3] = {a.x, a.y, b.x}, mx[3] = {b.y, c.x, c.y};
     if (!box_enter(mn, mx, sl, enter) || !(L.bound_before >= enter))
         __hip_atomic_store(S.limit_flag + (offsetof(GenCtrl, inexact) - offsetof(GenCtrl, limit)) / 4, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -874,7 +884,7 @@ RTX_DEV void job_finalize(const Scene& S, const ObjCache& oc, Lane& L, const Rec
     // (a job that the wave-wide traversal finished ends at a triangle of the reference-order array, found
     // through the exact four-wide boxes: nothing to check)
     const bool fast_key = B8 && L.btri >= S.t8_key0;
-    if (fast_key) b8_verify(S, L);
+    if (fast_key) b8_verify(S, L, Tg);
     const Obj* ob = oc.at(S, L.obj);
     if (!out.on && !(ob->flags & OBJ_XF)) {
         // a shadow ray keeps no record: of an untransformed hit only distance and flag remain
@@ -2662,8 +2672,15 @@ k_trace(const Launch* __restrict__ Lp, GenCtrl* ctrl, const int gen, double* __r
                   ((unsigned long long)((RTX_WAVE_TALLY == 2 ? clk_lane : clk_steps) * 100 / (long long)life) << 24) | ((unsigned long long)(clk_service * 100 / (long long)life) << 17) |
                   ((unsigned long long)(n_wide_jobs > 255u ? 255u : n_wide_jobs) << 9) | (n_passes > 511u ? 511u : n_passes));
         atomicAdd(&me->tally[12], 1u);
+        if (RTX_WAVE_TALLY == 4) {      // sums over all waves instead of the bins: ticks in traversal steps, service passes, wave-wide jobs; passes
+            atomicAdd((unsigned long long*)&me->tally[0], (unsigned long long)clk_steps);
+            atomicAdd((unsigned long long*)&me->tally[2], (unsigned long long)clk_service);
+            atomicAdd((unsigned long long*)&me->tally[4], (unsigned long long)clk_wide);
+            atomicAdd((unsigned long long*)&me->tally[6], (unsigned long long)n_passes);
+        } else {
         const unsigned bin = (unsigned)(life / (150ull * 2400ull));          // 150 us bins at 2.4 GHz
         atomicAdd(&me->tally[bin < 7u ? bin : 7u], 1u);
+        }
         // ... and how long the wave went on after it found the queue dry (sum and maximum)
         const unsigned long long after = (unsigned long long)(RTX_TICK() - clk_drained);
         atomicAdd((unsigned long long*)&me->tally[14], after);
