@@ -1,6 +1,6 @@
 """Dev helper (GPU box): one frame of a workload with per-generation timing lines, through whichever build of the
 library RTX_AMD_LIB names (tools/diag_build.sh: -DRTX_WAVE_TALLY=1..4 add wave lifetimes and section shares).
-Usage: RTX_AMD_LIB=build_diag/librtx_amd_tally4.so python tools/tally.py <workload> [wide]"""
+Usage: RTX_AMD_LIB=build_diag/librtx_amd_tally4.so python tools/tally.py <workload> [wide|counters]"""
 import os
 import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -11,11 +11,13 @@ from raytracer_amd import _abi  # noqa: E402
 
 name = sys.argv[1] if len(sys.argv) > 1 else "dragon_metal"
 wide = len(sys.argv) > 2 and sys.argv[2] == "wide"
+counters = len(sys.argv) > 2 and sys.argv[2] == "counters"      # the counting kernel's own section clocks
 path, _ = bench.make_workload(name, bench.scene_cache_dir())
 hs = rt.HostScene(path)
 ds = rt.DeviceScene(hs.desc, 0, wide_blas=wide)
 if wide:
     ds.set_wide_blas(True)
+ds.set_counters(counters)
 cam, _ = hs.camera(0)
 for _ in range(2):
     ds.render(cam)
