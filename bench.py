@@ -1103,6 +1103,8 @@ def main(argv=None) -> int:
     args = parse_args(argv)
     if args.gpus < 1:
         raise SystemExit("--gpus must be at least 1")
+    if args.steps < 1 or args.warmup < 0:
+        raise SystemExit("--steps must be at least 1 and --warmup at least 0")
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return launch_ranks(args.gpus, argv)
     if args.selftest_ranks:

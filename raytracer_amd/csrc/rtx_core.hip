@@ -1040,9 +1040,10 @@ int job_prepare(rtx_frame* fr, const rtx_camera* cam, int32_t tw, int32_t th, in
     // the scene's state as of now: flags, and the current version of the lights
     J.counters_on = sc->counters_on; J.consistent = sc->consistent; J.debug = sc->debug; J.wide_blas = sc->wide_blas;
     J.timing = sc->generation_timing || (sc->debug & RTX_DEBUG_GEN_TIMING);
-    J.dev = sc->dev;
     {
+        // (rtx_scene_update_lights writes the scene's light fields under the same lock)
         std::lock_guard<std::mutex> lock(sc->lights_mutex);
+        J.dev = sc->dev;
         J.lights = sc->lights;
     }
     J.dev.lights = (const Light*)J.lights->buf.p;
