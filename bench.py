@@ -923,6 +923,9 @@ def measure_sequence(R: Rank, args, name, steps, warmup, whole, inflight=1, pari
         warm = [(rank + (i - warmup) * world) % n_seq for i in range(warmup)]
     needed = sorted(set(range(n_seq)) if whole else set(f for r in range(world) for i in range(-warmup, steps)
                                                         for f in [(r + i * world) % n_seq]))
+    check_ranks = world > 1 or getattr(args, "multi_check", False)
+    if check_ranks and needed[0] != 0:
+        needed = [0] + needed           # (the frame every rank renders once for the self-check below)
     files = dict(zip(needed, R.workload(name, needed)))
     descr = files[needed[0]][1]
     R.note(f"sequence {name}: loading the geometry once per rank")
@@ -970,6 +973,7 @@ def measure_sequence(R: Rank, args, name, steps, warmup, whole, inflight=1, pari
     R.barrier()
     t0 = time.perf_counter()
     stats = render_all(mine)
+    own_s = time.perf_counter() - t0               # (this rank's own frames, before it waits for the others)
     R.barrier()
     elapsed = R.reduce([time.perf_counter() - t0], "max")[0]
     rays_mine = sum(int(s["rays"]) for s in stats)
@@ -994,6 +998,10 @@ def measure_sequence(R: Rank, args, name, steps, warmup, whole, inflight=1, pari
             parity = {"frames_checked": checked, "vs_oracle": {"identical_min": worst_same, "max_delta": worst_delta,
                                                                 "hit_mismatches": bad_hits,
                                                                 "pixels_per_frame": int(cam.width * cam.height)}}
+    # N > 1: the run checks itself (every rank seen, every rank's time, the same bytes for the same frame)
+    multi = None
+    if check_ranks:
+        multi = multi_rank_check(R, ds.render(next_frame(0))[0], own_s / max(len(mine), 1) * 1e3)
     out = None
     if rank == 0:
         per_rank = max(len(D.shard_frames(n_seq, r, world)) for r in range(world)) if whole else steps
@@ -1011,6 +1019,8 @@ def measure_sequence(R: Rank, args, name, steps, warmup, whole, inflight=1, pari
                "n_gpus": world}
         if parity is not None:
             out["parity_sampled"] = parity
+        if multi is not None:
+            out["multi_gpu"] = multi
     for fr, _ in slots:
         fr.close()
     ds.close()
@@ -1034,6 +1044,8 @@ def run_rank(args) -> int:
                               "sharding": seq["sharding"], "frames_per_step": world, "frames_per_s": seq["frames_per_s"],
                               "rays_per_step": seq["rays"] / args.steps, "resolution": seq["resolution"]},
                    "sequence": seq}
+            if seq.get("multi_gpu") is not None:
+                out["multi_gpu"] = seq["multi_gpu"]
     else:
         out = measure_static(R, args, args.workload, args.mode, args.steps, args.warmup,
                              with_cpu=(world == 1 and not args.no_cpu_baseline), pipelined=extras or args.pipelined)
