@@ -127,6 +127,67 @@ def test_frame_contract(unit_scenes):
     ds.close(); hs.close()
 
 
+def test_frame_contexts_from_several_host_threads(unit_scenes):
+    """Four host threads, each with a frame context of the same scene, render orbit cameras in a loop
+    while a fifth thread keeps publishing one of two light versions: every picture is the blocking call's
+    bytes for one of the two versions (a frame renders with the version current at its submit), the
+    blocking call itself may run beside them, and nothing is torn."""
+    import threading
+    hs = rt.HostScene(unit_scenes["marching_small"])
+    ds = rt.DeviceScene(hs.desc, 0)
+    cam, _ = hs.camera(0)
+    cams = [_orbit(cam, k, 5) for k in range(5)]
+    lights_a = hs.lights()
+    lights_b = [type(l).from_buffer_copy(l) for l in lights_a]
+    lights_b[0].intensity[0] *= 0.5
+    ds.update_lights(lights_b)
+    want_b = [ds.render(c)[0].copy() for c in cams]
+    ds.update_lights(lights_a)
+    want_a = [ds.render(c)[0].copy() for c in cams]
+    assert not np.array_equal(want_a[0], want_b[0])
+    errors, seen = [], {"a": 0, "b": 0}
+    stop = threading.Event()
+
+    def renderer(t):
+        try:
+            fr = ds.frame()
+            for i in range(24):
+                k = (t + i) % len(cams)
+                fr.submit(cams[k])
+                rgb, _, _ = fr.wait()
+                if np.array_equal(rgb, want_a[k]):
+                    seen["a"] += 1
+                elif np.array_equal(rgb, want_b[k]):
+                    seen["b"] += 1
+                else:
+                    errors.append((t, i, "a picture of neither light version"))
+            fr.close()
+        except Exception as e:                       # noqa: BLE001
+            errors.append((t, repr(e)))
+
+    def lights():
+        n = 0
+        while not stop.is_set():
+            ds.update_lights(lights_b if n % 2 == 0 else lights_a)
+            n += 1
+
+    threads = [threading.Thread(target=renderer, args=(t,)) for t in range(4)]
+    lt = threading.Thread(target=lights)
+    lt.start()
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join(timeout=120)
+    stop.set()
+    lt.join(timeout=30)
+    assert not errors, errors[:3]
+    assert not any(th.is_alive() for th in threads) and not lt.is_alive()
+    assert seen["a"] + seen["b"] == 4 * 24
+    ds.update_lights(lights_a)
+    assert np.array_equal(ds.render(cams[0])[0], want_a[0])
+    ds.close(); hs.close()
+
+
 def test_stacked_untransformed_instances(tmp_path):
     """64 untransformed instances of 64 small meshes behind one another, nearer ones with higher
     indices, all of them on every central ray: in the default mode (nearest-first search, from 32
