@@ -1,17 +1,23 @@
-#!/usr/bin/env python3
 """Dev helper (GPU box): per-generation kernel times of grass_desert in the three ways its instances can be
-taken -- exact mode's nearest-first search, the index-order replay (RTX_AMD_NO_SEARCH=1), consistent mode.
-Usage: tools/grass_modes_timing.py   (the figures come on stderr, RTX_AMD_GEN_TIMING lines)"""
-import os, sys
+taken -- exact mode's nearest-first search, the index-order replay (RTX_DEBUG_NO_SEARCH), consistent mode.
+Usage: python tools/grass_modes_timing.py   (the figures come on stderr)"""
+import os
+import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-os.environ["RTX_AMD_GEN_TIMING"] = "1"
-import bench, raytracer_amd as rt
+import bench  # noqa: E402
+import raytracer_amd as rt  # noqa: E402
+from raytracer_amd import _abi  # noqa: E402
+
 path, _ = bench.make_workload("grass_desert", bench.scene_cache_dir())
-hs = rt.HostScene(path); ds = rt.DeviceScene(hs.desc, 0); cam, _ = hs.camera(0)
-for label, cons, nos in (("search", False, False), ("replay", False, True), ("consistent", True, False)):
-    if nos: os.environ["RTX_AMD_NO_SEARCH"] = "1"
-    else: os.environ.pop("RTX_AMD_NO_SEARCH", None)
+hs = rt.HostScene(path)
+ds = rt.DeviceScene(hs.desc, 0)
+cam, _ = hs.camera(0)
+for label, cons, flags in (("search", False, 0), ("replay", False, _abi.DEBUG_NO_SEARCH), ("consistent", True, 0)):
     ds.set_consistent(cons)
+    ds.set_debug(flags)
     ds.render(cam)
     print("====", label, file=sys.stderr, flush=True)
-    ds.render(cam)
+    ds.set_debug(flags | _abi.DEBUG_GEN_TIMING)
+    _, _, st = ds.render(cam)
+    print(f"{label}: kernels {st['kernel_ms']:.2f} ms, records {st['record_fetches']}", file=sys.stderr, flush=True)
+ds.close(); hs.close()

@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Dev helper (GPU box): exact mode's instance search against the plain replay in index order, same
 library, same frame (the view reduced by `reduce_factor`): primary-hit records and pictures must be equal.
 Usage: tools/search_check.py <workload> [reduce_factor]"""
@@ -9,6 +8,7 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 import bench  # noqa: E402
 import raytracer_amd as rt  # noqa: E402
+from raytracer_amd import _abi  # noqa: E402
 
 name = sys.argv[1] if len(sys.argv) > 1 else "grass_desert"
 f = int(sys.argv[2]) if len(sys.argv) > 2 else 8
@@ -18,9 +18,9 @@ ds = rt.DeviceScene(hs.desc, 0)
 cam, _ = hs.camera(0)
 small = bench.reduced_camera(cam, f) if f > 1 else cam
 
-os.environ.pop("RTX_AMD_NO_SEARCH", None)
+ds.set_debug(0)
 a_rgb, a_hits, _ = ds.render(small, want_hits=True)
-os.environ["RTX_AMD_NO_SEARCH"] = "1"
+ds.set_debug(_abi.DEBUG_NO_SEARCH)
 b_rgb, b_hits, _ = ds.render(small, want_hits=True)
 bad = np.nonzero(a_hits != b_hits)[0]
 px = np.nonzero((a_rgb != b_rgb).any(axis=2).ravel())[0]
