@@ -211,22 +211,20 @@ int rtx_render(rtx_scene* scene, const rtx_camera* camera,
                uint8_t* rgb_out, int32_t rgb_is_device,
                rtx_hit_id* hit_ids, rtx_stats* stats);
 
-/* rtx_render for callers that cannot allocate device memory (tight serving loops, harnesses that
- * forbid hipMalloc, code that runs while another thread captures a HIP graph in relaxed mode).  It
- * has no counterpart in the reference.  Same arguments and results as rtx_render (no hit_ids), but
- * every byte of device
- * memory the frame needs beyond the scene and rgb_out -- ray queues, hit records, traversal
- * stacks, instance bitmaps, accumulators, control blocks -- comes from one fixed array of
- * rtx_noalloc_scratch_bytes() bytes (64 MiB) that the library holds on every GPU it runs on until
- * the process ends; the call makes no hipMalloc / hipFree and its trace grid is 32 blocks, so it
- * is meant for tiles, not for large frames.  The call itself is blocking (it records events, copies
- * its control blocks back and waits for its stream), so it cannot be captured into a graph.  What
- * fits: roughly pixels * (lights + 2) <= 150 000
- * queued rays (e.g. a 192 x 192 tile with two lights); a larger request fails with RTX_ELIMIT
- * and a message that states the bytes needed, a queue overflow at run time (deep dielectric
- * branching) fails with RTX_ENOMEM instead of growing the queues.  Pass page-locked or device
- * memory as rgb_out (the runtime stages copies into pageable memory itself).  Every call on a
- * GPU shares that GPU's array: calls that overlap on one GPU, from any scene or thread, race. */
+/* rtx_render for callers that cannot allocate device memory: tight serving loops, harnesses that
+ * forbid hipMalloc.  It has no counterpart in the reference.  Same arguments and results as
+ * rtx_render (no hit_ids), but every byte of device memory the frame needs beyond the scene and
+ * rgb_out -- ray queues, hit records, traversal stacks, instance bitmaps, accumulators, control
+ * blocks -- comes from one fixed array of rtx_noalloc_scratch_bytes() bytes (64 MiB) that the
+ * library holds on every GPU it runs on until the process ends; the call makes no hipMalloc /
+ * hipFree and its trace grid is 32 blocks, so it is meant for tiles, not for large frames.  The call
+ * is blocking (it records events, copies its control blocks back and waits for its stream), so it
+ * cannot itself be captured into a HIP graph.  What fits: roughly pixels * (lights + 2) <= 150 000
+ * queued rays (e.g. a 192 x 192 tile with two lights); a larger request fails with RTX_ELIMIT and a
+ * message that states the bytes needed, a queue overflow at run time (deep dielectric branching)
+ * fails with RTX_ENOMEM instead of growing the queues.  Pass page-locked or device memory as
+ * rgb_out (the runtime stages copies into pageable memory itself).  Every call on a GPU shares that
+ * GPU's array: calls that overlap on one GPU, from any scene or thread, race. */
 int rtx_render_noalloc(rtx_scene* scene, const rtx_camera* camera,
                        int32_t tile_w, int32_t tile_h, int32_t tile_first, int32_t tile_stride,
                        uint8_t* rgb_out, int32_t rgb_is_device, rtx_stats* stats);
@@ -245,9 +243,10 @@ int64_t rtx_noalloc_scratch_bytes(void);
  *   rtx_render_async   rtx_render's arguments (same meaning); returns once the work is queued.
  *                      rgb_out / hit_ids must stay valid until the wait; page-locked or device
  *                      memory keeps the final copy asynchronous.  One render per frame at a time.
- *   rtx_frame_wait     waits for the render, redoes it with larger queues if they overflowed
- *                      (as rtx_render does), fills `stats` (may be NULL).  The bytes are the same
- *                      as rtx_render's for the same camera.
+ *   rtx_frame_wait     waits for the render, redoes it with larger queues if they overflowed, or
+ *                      with the four-wide records if the eight-wide check failed (as rtx_render
+ *                      does), fills `stats` (may be NULL).  The bytes are the same as rtx_render's
+ *                      for the same camera.
  *   rtx_frame_destroy  waits for the frame's stream and frees the context.  Destroy a scene's
  *                      frames before the scene (rtx_scene_destroy frees the ones left).
  * A frame is used by one thread at a time; different frames of one scene may be used from
