@@ -180,6 +180,11 @@ typedef struct rtx_stats {
      * wide_blas_redone: 1 when its end-of-job check failed somewhere and the frame was rendered again
      * with the four-wide kernels (the picture returned is that second one). */
     uint32_t wide_blas, wide_blas_redone;
+    /* Of shadow_rays: those that no object of the scene could hold up -- every mesh and instance turns
+     * them down at its first box test -- and that the shading kernel therefore settled on the spot
+     * (isInShadow, utils.cpp:1066-1084, answers "no") instead of queueing them for the trace kernel.
+     * Default mode, scenes without planes, spheres and free triangles; 0 otherwise. */
+    uint64_t shadow_rays_settled_early;
 } rtx_stats;
 
 typedef struct rtx_scene rtx_scene;   /* opaque: owns the device copy of the scene */
@@ -366,7 +371,9 @@ enum {
                                         much of the kernel's time is latency that more waves would hide)   */
     RTX_DEBUG_FAIL_WIDE_BLAS_CHECK = 256, /* rtx_scene_set_wide_blas: behave as if the end-of-job check had failed (the
                                         frame is then redone with the four-wide kernels: exercises that path)    */
-    RTX_DEBUG_ALL = 511
+    RTX_DEBUG_NO_EARLY_SHADOW = 512, /* shadow rays that no object can hold up are queued and traced like the others
+                                     * instead of being settled where they are emitted                          */
+    RTX_DEBUG_ALL = 1023
 };
 int rtx_scene_set_debug(rtx_scene* scene, uint32_t flags);
 

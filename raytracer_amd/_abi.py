@@ -101,7 +101,8 @@ class Stats(C.Structure):
                 ("wave_inner_steps", C.c_uint64), ("wave_inner_lanes", C.c_uint64),
                 ("wave_leaf_steps", C.c_uint64), ("wave_leaf_lanes", C.c_uint64),
                 ("trace_ms", C.c_double), ("trace_launches", C.c_uint32), ("instance_path", C.c_uint32),
-                ("record_fetches", C.c_uint64), ("wide_blas", C.c_uint32), ("wide_blas_redone", C.c_uint32)]
+                ("record_fetches", C.c_uint64), ("wide_blas", C.c_uint32), ("wide_blas_redone", C.c_uint32),
+                ("shadow_rays_settled_early", C.c_uint64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -120,6 +121,7 @@ AMD_SYMBOLS = ["rtx_build_bvh", "rtx_scene_create", "rtx_scene_update_lights", "
 # rtx_scene_set_debug switches (include/rtx_amd.h)
 DEBUG_NO_SCATTER, DEBUG_POISON_QUEUES, DEBUG_GEN_TIMING, DEBUG_NO_WIDE = 1, 2, 4, 8
 DEBUG_NO_SEARCH, DEBUG_NO_WIDE_OLD, DEBUG_ALL_GENERATIONS, DEBUG_HALF_GRID, DEBUG_FAIL_WIDE_BLAS_CHECK = 16, 32, 64, 128, 256
+DEBUG_NO_EARLY_SHADOW = 512
 SCENE_WIDE_BLAS = 1          # rtx_scene_desc::build_flags
 HOST_SYMBOLS = ["rtx_host_load", "rtx_host_load_next", "rtx_host_attach_bvh", "rtx_host_desc", "rtx_host_camera_count", "rtx_host_camera",
                 "rtx_host_timings", "rtx_host_dump", "rtx_host_free", "rtx_host_write_ppm",

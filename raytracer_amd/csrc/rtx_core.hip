@@ -969,6 +969,7 @@ uint32_t debug_from_environment() {
         if (getenv("RTX_AMD_NO_WIDE_OLD")) f |= RTX_DEBUG_NO_WIDE_OLD;
         if (getenv("RTX_AMD_ALL_GENERATIONS")) f |= RTX_DEBUG_ALL_GENERATIONS;
         if (getenv("RTX_AMD_HALF_GRID")) f |= RTX_DEBUG_HALF_GRID;
+        if (getenv("RTX_AMD_NO_EARLY_SHADOW")) f |= RTX_DEBUG_NO_EARLY_SHADOW;
         return f;
     }();
     return flags;
@@ -1292,7 +1293,15 @@ int job_start_attempt(rtx_frame* fr) {
                             nest ? "consistent" : search ? "search" : "off", (int)sc->affine_insts, sc->nest_stack_need);
     // ... and, in scenes that are not dominated by instance replay, of the long-running jobs of
     // every generation's drained waves (a kernel variant of its own; see k_trace)
-    launch.chunk_max = replay_heavy ? RTX_CHUNK_INSTANCED : RTX_CHUNK; launch.pad_launch = 0;
+    launch.chunk_max = replay_heavy ? RTX_CHUNK_INSTANCED : RTX_CHUNK;
+    // shadow rays that no object can hold up are settled by the shading kernel (shadow_ray_is_free): default mode
+    // only (with counters on every query is carried out; the consistent mode's bound is the light's distance)
+    {
+        const int n_lin = J.dev.n_meshes + (J.dev.n_insts <= RTX_LINEAR_INSTS ? J.dev.n_insts : 0);
+        launch.early_shadow = (!J.counters_on && !J.consistent && !(J.debug & RTX_DEBUG_NO_EARLY_SHADOW) &&
+                               J.dev.n_planes == 0 && J.dev.n_spheres == 0 && J.dev.n_ftris == 0 && n_lin <= 16 &&
+                               J.dev.n_lights <= 32) ? 1u : 0u;
+    }
     launch.wide_old = (launch.wide_ok && J.dev.n_insts < 256 && !(J.debug & RTX_DEBUG_NO_WIDE_OLD)) ? 1u : 0u;
     HIP_TRY(hipMemcpyAsync(M.launch, &launch, sizeof launch, hipMemcpyHostToDevice, fr->stream));
 
@@ -1529,7 +1538,7 @@ int frame_wait(rtx_frame* fr, rtx_stats* stats) {
                 primary += (uint64_t)std::max(0, std::min(J.tw, J.cam.width - x0)) * (uint64_t)std::max(0, std::min(J.th, J.cam.height - y0));
             }
             for (int k = 1; k <= G; k++)
-                for (const SubCount& sub : ctrl[k].sub) { radiance += sub.counts & 0xFFFFFFFFull; shadow += sub.counts >> 32; }
+                for (const SubCount& sub : ctrl[k].sub) { radiance += sub.counts & 0xFFFFFFFFull; shadow += (sub.counts >> 32) + sub.early; }
             stats->primary_rays = primary; stats->secondary_rays = radiance; stats->shadow_rays = shadow;
             stats->rays = primary + radiance + shadow;
         }
@@ -1541,6 +1550,8 @@ int frame_wait(rtx_frame* fr, rtx_stats* stats) {
         stats->kernel_ms = J.kernel_ms;
         stats->trace_ms = J.trace_ms; stats->trace_launches = J.trace_launches; stats->instance_path = J.instance_path;
         stats->wide_blas = J.b8 ? 1u : 0u; stats->wide_blas_redone = J.no_b8 ? 1u : 0u;
+        for (int k = 1; k <= G; k++)
+            for (const SubCount& sub : ctrl[k].sub) stats->shadow_rays_settled_early += sub.early;
         for (int k = 0; k <= G; k++) stats->record_fetches += ctrl[k].records;
         stats->total_ms = std::chrono::duration<double, std::milli>(std::chrono::high_resolution_clock::now() - J.wall0).count();
     }

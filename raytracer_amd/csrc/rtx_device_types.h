@@ -215,7 +215,9 @@ struct HitBuf { Hit* recs; };
 // rays (high half) of its sub-queue, so that one 64-bit atomic reserves slots at either end of
 // the sub-queue and observes the other end's fill level at the same instant.
 #define RTX_NSUB 16
-struct alignas(128) SubCount { unsigned long long counts; unsigned long long pad[15]; };
+// early: shadow rays of this sub-queue's appending waves that were settled where they would have been
+// emitted (k_shade, shadow_ray_is_free) and never queued -- they count as rays all the same.
+struct alignas(128) SubCount { unsigned long long counts; unsigned long long early; unsigned long long pad[14]; };
 // overflow: a reservation in one of this generation's sub-queues did not fit -- the generation's
 // rays are incomplete, its kernels and those of every later generation return at once (the flag is
 // handed on from control block to control block) and the host renders the frame again with
@@ -265,7 +267,9 @@ struct Launch {
     // In generations of size, drained waves finish their long-running jobs wave-wide as well.
     uint32_t wide_old;
     // Largest number of rays a wave of the trace kernel claims at once.
-    uint32_t chunk_max, pad_launch;
+    uint32_t chunk_max;
+    // The shading kernel settles a shadow ray that every object turns down at its first test (no queue, no trace).
+    uint32_t early_shadow;
 };
 
 struct Counters {

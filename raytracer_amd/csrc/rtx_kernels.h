@@ -826,6 +826,41 @@ RTX_DEV int job_next(const Scene& S, const ObjCache& oc, Lane& L, const RecOut& 
     }
 }
 
+// A shadow ray that nothing in the scene can hold up, decided where the ray would be emitted: every mesh
+// and instance turns it down at the FIRST test job_next would make for it -- the world box of a
+// transformed object (utils.cpp:446-466, 760-766), the root box of an untransformed one (bvh.cpp:132), the
+// TLAS root for instances beyond the linear few -- with the same arithmetic on the same origin and
+// direction the queue would carry, and the bound a fresh shadow ray has in the default mode (DBL_MAX:
+// every entry distance is below it).  Such a ray runs no job, accepts no hit and ends by adding its
+// unshadowed contribution (service_lane, "ray complete"), which the caller does at once instead.
+// Only for scenes without planes, spheres and free triangles (the host decides: Launch::early_shadow);
+// anything not plainly turned down -- an object without a world box, a box test that passes -- leaves the
+// ray to the trace kernel.
+RTX_DEV bool shadow_ray_is_free(const Scene& S, V3 o, V3 d) {
+    const Slab ws = make_slab(o, d);
+    const int n_lin = S.n_meshes + (S.n_insts <= RTX_LINEAR_INSTS ? S.n_insts : 0);
+    for (int oi = 0; oi < n_lin; oi++) {
+        const RTX_GLOBAL v2d* p2 = (const RTX_GLOBAL v2d*)((const RTX_GLOBAL Obj*)S.objs + oi)->bmin;
+        double ob2[14];
+#pragma unroll
+        for (int k = 0; k < 7; k++) { const v2d v = p2[k]; ob2[2 * k] = v.x; ob2[2 * k + 1] = v.y; }
+        const int flags = __double2loint(ob2[13]);
+        if (flags & OBJ_SKIP) continue;
+        double enter;
+        if (flags & OBJ_XF) {
+            if (!(flags & OBJ_BOUNDS) || box_enter(ob2 + 0, ob2 + 3, ws, enter)) return false;
+        } else if (box_enter(ob2 + 6, ob2 + 9, ws, enter)) {
+            return false;
+        }
+    }
+    if (S.n_insts > RTX_LINEAR_INSTS) {
+        double tl_min[3] = {S.tl_min[0], S.tl_min[1], S.tl_min[2]}, tl_max[3] = {S.tl_max[0], S.tl_max[1], S.tl_max[2]};
+        double enter;
+        if (box_enter(tl_min, tl_max, ws, enter)) return false;
+    }
+    return true;
+}
+
 // Instances entered from the walk of the TLAS (see traverse_steps, NEST), after a job that found
 // something: back to the walk with the world-space ray.  Returns 1 if the walk has entries left
 // (the lane asks for a pop), 0 if the ray has seen every instance it can meet.
@@ -2886,9 +2921,25 @@ k_shade(const Launch* __restrict__ Lp, GenCtrl* ctrl, const int gen, double* __r
         // Light loop: one shadow ray per light for conductor and plain materials, carrying the
         // unshadowed contribution (utils.cpp:887-913, 1008-1038); isInShadow: utils.cpp:1066-1084.
         const bool lit = shade && mtype != RTX_MAT_DIELECTRIC;
-        const unsigned n_lit = (unsigned)__popcll(__ballot(lit));
-        const Emit em = emit_reserve(qout, next, my_sub, (unsigned)__popcll(__ballot(c0)) + (unsigned)__popcll(__ballot(c1)),
-                                     n_lit * (unsigned)S.n_lights);
+        // Which of this hit's shadow rays nothing can hold up (bit li: light li): those add their
+        // contribution below instead of being queued.  The reservation needs the count first.
+        const V3 s_origin = vadd(P, sscale(S.shadow_eps, gn));
+        unsigned free_lights = 0u, n_queued = 0u, n_early = 0u;
+        if (Lp->early_shadow != 0u) {
+            for (int li = 0; li < S.n_lights; li++) {
+                bool is_free = false;
+                if (lit) is_free = shadow_ray_is_free(S, s_origin, normalize(vsub(ld3(S.lights[li].p), P)));
+                free_lights |= is_free ? (1u << li) : 0u;
+                const unsigned n_free = (unsigned)__popcll(__ballot(is_free));
+                n_early += n_free;
+                n_queued += (unsigned)__popcll(__ballot(lit)) - n_free;
+            }
+        } else {
+            n_queued = (unsigned)__popcll(__ballot(lit)) * (unsigned)S.n_lights;
+        }
+        const Emit em = emit_reserve(qout, next, my_sub, (unsigned)__popcll(__ballot(c0)) + (unsigned)__popcll(__ballot(c1)), n_queued);
+        if (n_early != 0u && lane == 0u) atomicAdd(&next->sub[my_sub].early, (unsigned long long)n_early);
+        unsigned sh_at = em.sh;                     // first slot of the next light's rays (wave-uniform)
         for (int li = 0; li < S.n_lights; li++) {
             V3 so = P, sd = d, sw = W;
             double dist_to_light = 0.0;
@@ -2909,12 +2960,14 @@ k_shade(const Launch* __restrict__ Lp, GenCtrl* ctrl, const int gen, double* __r
                     V3 diffuse = vscale(vscale(vmul(lobe_a, ld3(L.i)), df), atten);
                     contrib = vadd(diffuse, contrib);
                 }
-                so = vadd(P, sscale(S.shadow_eps, gn));
+                so = s_origin;
                 sd = normalize(vsub(lp, P));
                 sw = vmul(W, contrib);
                 dist_to_light = sqrt(dot(vsub(lp, P), vsub(lp, P)));
             }
-            emit(qout, my_sub, em, em.sh + (unsigned)li * n_lit, true, lit, so, sd, sw, dist_to_light, pixel, 0u);
+            const bool settled = lit && ((free_lights >> li) & 1u) != 0u;
+            if (settled) add_color(accum, pixel, sw);                          // utils.cpp:1083: not in shadow
+            sh_at += emit(qout, my_sub, em, sh_at, true, lit && !settled, so, sd, sw, dist_to_light, pixel, 0u);
         }
         const unsigned n_c0 = emit(qout, my_sub, em, em.rad, false, c0, c0o, c0d, c0w, 0.0, pixel, RTX_META(depth + 1, -1));
         emit(qout, my_sub, em, em.rad + n_c0, false, c1, c1o, c1d, c1w, 0.0, pixel, RTX_META(depth + 1, c1beer));

@@ -9,7 +9,7 @@ import pytest
 
 import _checkers as ck
 import raytracer_amd as rt
-from raytracer_amd import scenes
+from raytracer_amd import _abi, scenes
 
 pytestmark = pytest.mark.gpu
 
@@ -34,6 +34,11 @@ def test_random_scene_matches_oracle(tmp_path, seed):
         assert mx <= 2 and same >= 0.999, (seed, counters, same, mx)
         if counters:
             assert st["rays"] == o_ctr["rays"] and st["tri_tests"] == o_ctr["tri_tests"], (seed, st, o_ctr)
+    # (the default-mode frame above settled its free shadow rays in the shading kernel; once with all of them traced)
+    ds.set_debug(_abi.DEBUG_NO_EARLY_SHADOW)
+    q_rgb, q_hits, q_st = ds.render(cam, want_hits=True)
+    ds.set_debug(0)
+    assert np.array_equal(q_hits, hits) and np.array_equal(q_rgb, rgb) and q_st["rays"] == st["rays"], (seed, "every shadow ray traced")
     ds.set_wide_blas(True)
     w_rgb, w_hits, w_st = ds.render(cam, want_hits=True)
     assert np.array_equal(w_hits, hits) and np.array_equal(w_rgb, rgb), (seed, "eight-wide records")

@@ -253,3 +253,39 @@ def test_wide_blas_redo_path(unit_scenes):
     rgb, hits, st = ds.render(cam, want_hits=True)
     assert st["wide_blas"] == 1 and st["wide_blas_redone"] == 0 and np.array_equal(rgb, ref)
     ds.close(); hs.close()
+
+
+# ---- shadow rays that no object can hold up, settled by the shading kernel instead of being traced ----
+@pytest.mark.parametrize("name", ["tiny", "bumpy_small", "david_small", "plates_small", "marching_small", "grass_small", "buried"])
+def test_shadow_rays_settled_early_change_nothing(unit_scenes, name):
+    """isInShadow (utils.cpp:1066-1084) for a ray that every mesh and instance turns down at its first
+    box test: the default path answers it where the ray would be emitted.  Same bytes, same hit records
+    and the same ray counts as with every shadow ray queued and traced (RTX_DEBUG_NO_EARLY_SHADOW), and
+    the oracle's ray count; in the consistent mode and with counters on nothing is settled early."""
+    from raytracer_amd import _abi
+    if name not in unit_scenes:
+        pytest.skip("no such unit scene")
+    hs = rt.HostScene(unit_scenes[name])
+    ds = rt.DeviceScene(hs.desc, 0)
+    cam, _ = hs.camera(0)
+    rgb, hits, st = ds.render(cam, want_hits=True)
+    ds.set_debug(_abi.DEBUG_NO_EARLY_SHADOW)
+    q_rgb, q_hits, q_st = ds.render(cam, want_hits=True)
+    ds.set_debug(0)
+    assert q_st["shadow_rays_settled_early"] == 0
+    assert np.array_equal(rgb, q_rgb) and np.array_equal(hits, q_hits), name
+    for k in ("rays", "primary_rays", "shadow_rays", "secondary_rays"):
+        assert st[k] == q_st[k], (name, k)
+    assert st["shadow_rays_settled_early"] <= st["shadow_rays"]
+    d = hs.desc.contents
+    if d.n_planes == 0 and d.n_spheres == 0 and d.n_triangles == 0 and name in ("tiny", "david_small", "bumpy_small"):
+        assert st["shadow_rays_settled_early"] > 0, (name, st)
+    _, _, o_ctr, _ = ck.oracle_render(hs.desc, cam, want_hits=False)
+    assert st["rays"] == o_ctr["rays"]
+    ds.set_counters(True)
+    assert ds.render(cam)[2]["shadow_rays_settled_early"] == 0
+    ds.set_counters(False)
+    ds.set_consistent(True)
+    assert ds.render(cam)[2]["shadow_rays_settled_early"] == 0
+    ds.close(); hs.close()
+
