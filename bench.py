@@ -166,16 +166,19 @@ def reference_bytes(c) -> int:
             + 384 * c["transformed_hits"] + 96 * c["rays"])
 
 
-def device_bytes(st, record_fetches=None) -> int:
+def device_bytes(st, record_fetches=None, settled_early=0) -> int:
     """A frame in the device's own records.  With `record_fetches` (rtx_stats.record_fetches of the
     timed frames, counted by the trace kernel in every mode): 256 bytes per record the traversal
     fetched -- collapsed nodes, triangle pairs, instance set-up records -- plus 96 bytes of ray
-    record in per queued ray and 128 bytes of hit record out per radiance ray.  Without it, the
+    record in per queued ray (`settled_early` of the rays were not) and 128 bytes of hit record out
+    per radiance ray.  Without it, the
     same from the work counters of a counters-on frame (every test of the reference carried out):
     256 bytes per BLAS or TLAS record visit, 128 per triangle test, world-box test and ray taken
     to object space."""
     radiance = st["rays"] - st["shadow_rays"]
-    rays_io = 96 * (st["rays"] - st["primary_rays"]) + 128 * radiance
+    # (shadow rays the shading kernel settled where it would have emitted them were never queued:
+    # rtx_stats.shadow_rays_settled_early of the timed frames)
+    rays_io = 96 * (st["rays"] - st["primary_rays"] - int(settled_early)) + 128 * radiance
     if record_fetches is not None:
         return int(256 * record_fetches) + rays_io
     return (256 * (st["node_visits"] + st["tlas_node_visits"]) + 128 * st["tri_tests"] + 128 * st["world_box_tests"]
@@ -768,7 +771,8 @@ def measure_static(R: Rank, args, name, mode, steps, warmup, with_cpu, pipelined
         # them in index order); the arithmetic model, built on the counters, is scaled by the same ratio.
         rec_timed = sum(s_["record_fetches"] for s_ in stats) / max(len(stats), 1)
         rec_counted = max(int(cst["record_fetches"]), 1)
-        dev_b = device_bytes(cst, rec_timed)
+        early_timed = sum(s_["shadow_rays_settled_early"] for s_ in stats) / max(len(stats), 1)
+        dev_b = device_bytes(cst, rec_timed, early_timed)
         flops = flops_counted * (rec_timed / rec_counted)
         # Dominant kernel: k_trace, the closest-hit traversal, launched once per ray generation (two
         # variants per generation, one of which returns at once).  Every generation's launches are
@@ -815,8 +819,9 @@ def measure_static(R: Rank, args, name, mode, steps, warmup, with_cpu, pipelined
             "reference_bytes_per_frame": ref_b, "reference_bytes_source": alg_source,
             "device_bytes_per_frame": dev_b,
             "device_bytes_source": "records the trace kernel fetched in the timed frames (rtx_stats.record_fetches, counted in "
-                                   "every mode) x 256 B, + 96 B per queued ray + 128 B per hit record",
+                                   "every mode) x 256 B, + 96 B per queued ray (shadow rays settled by the shading kernel are not queued) + 128 B per hit record",
             "record_fetches_per_frame": rec_timed,
+            "shadow_rays_settled_early_per_frame": early_timed,
             "record_fetches_per_frame_counters_on": rec_counted,
             "instance_path": {0: "candidates replayed in index order", 1: "nearest-first search with verification (identical "
                               "results; rtx_kernels.h, search_service)", 2: "consistent mode's nearest-first walk"}.get(
