@@ -156,6 +156,13 @@ RTX_DEV bool box_enter_nopar(const double* mn, const double* mx, const Slab& s, 
     return t1 >= t0;
 }
 
+// The box test of the service code (object world boxes, root boxes): nearly every ray has no
+// axis-parallel component, and for those the branch-free form gives the same values.
+RTX_DEV bool box_enter_svc(const double* mn, const double* mx, const Slab& s, double& enter) {
+    if ((s.par & RTX_PAR_AXES) == 0) return box_enter_nopar(mn, mx, s, enter);
+    return box_enter(mn, mx, s, enter);
+}
+
 // utils.cpp:327-370 on a pre-gathered triangle (a, e1 = b-a, e2 = c-a).  Accept iff
 // t < t_min (strict).  Back-face culling (utils.cpp:322-326) is applied by the caller.
 RTX_DEV bool tri_test(const double* T, V3 o, V3 d, double t_min, double eps, double& t_out,
@@ -638,7 +645,7 @@ RTX_DEV int job_next(const Scene& S, const ObjCache& oc, Lane& L, const RecOut& 
                     L.word = 0; L.whi = -1;
                     double tl_min[3] = {S.tl_min[0], S.tl_min[1], S.tl_min[2]}, tl_max[3] = {S.tl_max[0], S.tl_max[1], S.tl_max[2]};
                     double enter;
-                    if (!box_enter(tl_min, tl_max, ws, enter) || !(L.t_min * 1.000001 >= enter)) return 0;
+                    if (!box_enter_svc(tl_min, tl_max, ws, enter) || !(L.t_min * 1.000001 >= enter)) return 0;
                     L.obj = -1;
                     L.is_shadow &= 1;
                     if (NEST == 1 && L.is_shadow) L.dist = L.t_min;      // a shadow ray's bound in world space, for the way back from an instance
@@ -665,7 +672,7 @@ RTX_DEV int job_next(const Scene& S, const ObjCache& oc, Lane& L, const RecOut& 
                 } else if (S.n_insts > 0) {
                     double tl_min[3] = {S.tl_min[0], S.tl_min[1], S.tl_min[2]}, tl_max[3] = {S.tl_max[0], S.tl_max[1], S.tl_max[2]};
                     double enter;
-                    if (box_enter(tl_min, tl_max, ws, enter) && (L.t_min >= enter)) {
+                    if (box_enter_svc(tl_min, tl_max, ws, enter) && (L.t_min >= enter)) {
                         L.obj = -1;                                  // marks the job as the TLAS walk
                         L.is_shadow &= 1;
                         if (!COUNT && NEST != 2) L.age = 0;
@@ -719,7 +726,7 @@ RTX_DEV int job_next(const Scene& S, const ObjCache& oc, Lane& L, const RecOut& 
             // order and what an accepted hit writes are the job's (root box of bvh.cpp:132, leaf
             // triangles in order, utils.cpp:370-381 and 427-442).
             double enter;
-            if (!box_enter(ob2 + 6, ob2 + 9, ws, enter) || !(L.t_min >= enter)) continue;
+            if (!box_enter_svc(ob2 + 6, ob2 + 9, ws, enter) || !(L.t_min >= enter)) continue;
             const double* T = oc.tiny + ((flags >> 8) - 1) * 32;
             int won = -1;
             double beta = 0.0, gamma = 0.0;
@@ -750,12 +757,13 @@ RTX_DEV int job_next(const Scene& S, const ObjCache& oc, Lane& L, const RecOut& 
             continue;
         }
         V3 ro = L.o, rd = L.d;
+        V3 od = L.d;                                                 // the direction in object space, before it is normalised
         double bound = L.t_min;
         if (flags & OBJ_XF) {
             if (flags & OBJ_BOUNDS) {                                // utils.cpp:446-466, 760-766
                 if (COUNT) tl.world_box++;
                 double enter;
-                if (!box_enter(ob2 + 0, ob2 + 3, ws, enter) || !(L.t_min >= enter)) continue;
+                if (!box_enter_svc(ob2 + 0, ob2 + 3, ws, enter) || !(L.t_min >= enter)) continue;
             }
             if (COUNT) tl.obj_trav++;
             double inv[16];
@@ -765,18 +773,18 @@ RTX_DEV int job_next(const Scene& S, const ObjCache& oc, Lane& L, const RecOut& 
                 for (int k = 0; k < 8; k++) { const v2d v = p1[k]; inv[2 * k] = v.x; inv[2 * k + 1] = v.y; }
             }
             ro = xf_point(inv, L.o);                                 // utils.cpp:481-489
-            rd = normalize_f32(xf_dir(inv, L.d));
+            od = xf_dir(inv, L.d);
+            rd = normalize_f32(od);
             if (FAST) {
                 // consistent mode: the bound goes to object space with the ray (the divisor is the
                 // factor normalize_f32 applied to the direction)
-                const V3 od = xf_dir(inv, L.d);
                 bound = L.t_min / (1.0 / (double)sqrtf((float)(od.x * od.x + od.y * od.y + od.z * od.z)));
             }
         }
         // (an untransformed object is met by the world-space ray: same constants, no second set of divisions)
         const Slab sl = (flags & OBJ_XF) ? make_slab(ro, rd) : ws;
         double enter;
-        if (!box_enter(ob2 + 6, ob2 + 9, sl, enter) || !(bound >= enter)) continue;
+        if (!box_enter_svc(ob2 + 6, ob2 + 9, sl, enter) || !(bound >= enter)) continue;
         L.obj = oi;
         L.orig_t_min = L.t_min;
         if (FAST) L.t_min = bound;
@@ -790,7 +798,6 @@ RTX_DEV int job_next(const Scene& S, const ObjCache& oc, Lane& L, const RecOut& 
             // started with and the light's distance means the job ends with an accepted hit nearer
             // than the light, which decides the ray (see the untransformed case below).  The
             // threshold, rounded down to float, rides in the spare half of the context's pixel word.
-            const V3 od = xf_dir(ob->inv, L.d);
             const double f = 1.0 / (double)sqrtf((float)(od.x * od.x + od.y * od.y + od.z * od.z));
             const double thr = smin(L.t_min, light_dist) / (f * 1.000001);
             float thr_f = (float)thr;
@@ -848,15 +855,15 @@ RTX_DEV bool shadow_ray_is_free(const Scene& S, V3 o, V3 d) {
         if (flags & OBJ_SKIP) continue;
         double enter;
         if (flags & OBJ_XF) {
-            if (!(flags & OBJ_BOUNDS) || box_enter(ob2 + 0, ob2 + 3, ws, enter)) return false;
-        } else if (box_enter(ob2 + 6, ob2 + 9, ws, enter)) {
+            if (!(flags & OBJ_BOUNDS) || box_enter_svc(ob2 + 0, ob2 + 3, ws, enter)) return false;
+        } else if (box_enter_svc(ob2 + 6, ob2 + 9, ws, enter)) {
             return false;
         }
     }
     if (S.n_insts > RTX_LINEAR_INSTS) {
         double tl_min[3] = {S.tl_min[0], S.tl_min[1], S.tl_min[2]}, tl_max[3] = {S.tl_max[0], S.tl_max[1], S.tl_max[2]};
         double enter;
-        if (box_enter(tl_min, tl_max, ws, enter)) return false;
+        if (box_enter_svc(tl_min, tl_max, ws, enter)) return false;
     }
     return true;
 }
@@ -1066,7 +1073,7 @@ RTX_DEV int search_enter(const Scene& S, const ObjCache& oc, Lane& L, const int 
     if (flags & OBJ_XF) {
         if (flags & OBJ_BOUNDS) {
             double enter;
-            if (!box_enter(ob2 + 0, ob2 + 3, ws, enter) || !(bound >= enter)) return 0;
+            if (!box_enter_svc(ob2 + 0, ob2 + 3, ws, enter) || !(bound >= enter)) return 0;
         }
         double inv[16];
         {
@@ -1079,7 +1086,7 @@ RTX_DEV int search_enter(const Scene& S, const ObjCache& oc, Lane& L, const int 
     }
     const Slab sl = (flags & OBJ_XF) ? make_slab(ro, rd) : ws;
     double enter;
-    if (!box_enter(ob2 + 6, ob2 + 9, sl, enter) || !(bound >= enter)) return 0;
+    if (!box_enter_svc(ob2 + 6, ob2 + 9, sl, enter) || !(bound >= enter)) return 0;
     L.obj = oi;
     L.word = L.sp;
     L.orig_t_min = L.t_min;
@@ -2029,7 +2036,7 @@ RTX_DEV unsigned long long traverse_steps(const Scene& S, const Wave& wv, Lane& 
                 double bound = NEST == 2 ? L.dist : L.t_min;
                 if (NEST == 2 && enter_it && (flags & OBJ_XF) && (flags & OBJ_BOUNDS)) {
                     double e;
-                    enter_it = box_enter(rec + 16, rec + 19, sl, e) && (bound >= e);
+                    enter_it = box_enter_svc(rec + 16, rec + 19, sl, e) && (bound >= e);
                 }
                 V3 ro = L.o, rd = L.d;
                 if (enter_it && (flags & OBJ_XF)) {
@@ -2048,7 +2055,7 @@ RTX_DEV unsigned long long traverse_steps(const Scene& S, const Wave& wv, Lane& 
                 if (enter_it) {
                     const Slab os = (flags & OBJ_XF) ? make_slab(ro, rd) : sl;
                     double e;
-                    enter_it = box_enter(rec + 22, rec + 25, os, e) && (bound >= e);
+                    enter_it = box_enter_svc(rec + 22, rec + 25, os, e) && (bound >= e);
                     if (enter_it) {
                         L.obj = oi;
                         L.word = L.sp;
