@@ -496,6 +496,15 @@ enum { LS_EMPTY = 0, LS_NEED_JOB = 1, LS_JOB_DONE = 2, LS_IN_JOB = 3 };
 #ifndef RTX_SCATTER_SHIFT
 #define RTX_SCATTER_SHIFT 12         // rays of later generations are handed out in scattered groups of 4096 (finer costs locality)
 #endif
+#ifndef RTX_INST_QUORUM
+#define RTX_INST_QUORUM 16           // lanes at an instance slot that are waited for before the wave runs the instance set-up (1: none)
+#endif
+#ifndef RTX_LEAF_QUORUM
+#define RTX_LEAF_QUORUM 16           // ... lanes at leaves, before it runs the triangle tests
+#endif
+#ifndef RTX_NODE_QUORUM
+#define RTX_NODE_QUORUM 16           // ... lanes at nodes, before it runs the box tests
+#endif
 #ifndef RTX_CHUNK
 #define RTX_CHUNK 64                 // rays a wave claims per atomic, at most ...
 #endif
@@ -1984,7 +1993,26 @@ RTX_DEV unsigned long long traverse_steps(const Scene& S, const Wave& wv, Lane& 
         const long long k_f0 = RTX_TICK();
 #endif
         double rec[32];
-        const bool wants = in_job && !(NEST && L.cur_cnt == -1);      // (a lane that only asks for a pop fetches nothing)
+        // NEST: setting an instance up (transform, reciprocals, two box tests) is some three hundred vector
+        // instructions that the whole wave issues whenever ONE lane stands at an instance slot -- nearly every
+        // step in a scene of thousands of instances.  Such lanes wait (they fetch nothing and do nothing this
+        // step) until RTX_INST_QUORUM of them have gathered or no other lane has anything to do.
+        // The same for the other kinds of step in these kernels (the ones that walk a TLAS of many instances; in
+        // the plain mesh kernels holding lanes back costs more than the sections it saves): the wave runs a section
+        // (four box tests for the lanes at nodes, two triangle tests for the lanes at leaves) for the most numerous
+        // kind in any case, and for another kind only once enough of its lanes have gathered.
+        bool held = false;
+        if (!COUNT && NEST && (RTX_INST_QUORUM > 1 || RTX_LEAF_QUORUM > 1 || RTX_NODE_QUORUM > 1)) {
+            const bool k_inst = in_job && L.cur_cnt == -2, k_node = in_job && L.cur_cnt == 0;
+            const int n_inst = __popcll(__ballot(k_inst)), n_node = __popcll(__ballot(k_node)), n_leaf = __popcll(__ballot(at_leaf));
+            const int top = max(n_inst, max(n_node, n_leaf));
+            const bool run_inst = n_inst >= RTX_INST_QUORUM || n_inst == top;
+            const bool run_node = n_node >= RTX_NODE_QUORUM || n_node == top;
+            const bool run_leaf = n_leaf >= RTX_LEAF_QUORUM || n_leaf == top;
+            held = (k_inst && !run_inst) || (k_node && !run_node) || (at_leaf && !run_leaf);
+        }
+        const bool act = in_job && !held;
+        const bool wants = act && !(NEST && L.cur_cnt == -1);      // (a lane that only asks for a pop fetches nothing)
         // NEST: a lane whose entry is an instance fetches the set-up half of that instance's object record
         const int key = (NEST && L.cur_cnt == -2) ? S.obj_key0 + 4 * (S.n_meshes + L.cur_ref) : L.cur_ref;
 #ifndef RTX_NO_RECORD_COUNT
@@ -2018,7 +2046,7 @@ RTX_DEV unsigned long long traverse_steps(const Scene& S, const Wave& wv, Lane& 
         const bool nl = NEST == 1 || (NEST == 2 && !(L.age & SP_REPLAY));
         double t_cmp = 0.0;
         if (NEST) t_cmp = (nl && L.obj == -1) ? L.t_min * 1.000001 : L.t_min;
-        if (in_job) {
+        if (act) {
             if (NEST != 2) L.age++;       // (the search keeps its phase there)
             if (NEST && L.cur_cnt == -1) {
                 need_pop = true;
