@@ -1955,8 +1955,8 @@ RTX_DEV unsigned long long traverse_steps(const Scene& S, const Wave& wv, Lane& 
     const char* const blas = S.blas;
     const bool cull = S.cull != 0;
     const double isect_eps = S.isect_eps;
-    Slab sl;
-    sl.ox = L.ro.x; sl.oy = L.ro.y; sl.oz = L.ro.z; sl.ix = L.ix; sl.iy = L.iy; sl.iz = L.iz; sl.par = L.par;
+    // (the slab constants of the lane's current job are the lane's own fields: no second copy to keep in step)
+#define RTX_SL (Slab{L.ro.x, L.ro.y, L.ro.z, L.ix, L.iy, L.iz, L.par})
 
     while (true) {
         const bool in_job = L.state == LS_IN_JOB;
@@ -2064,7 +2064,7 @@ RTX_DEV unsigned long long traverse_steps(const Scene& S, const Wave& wv, Lane& 
                 double bound = NEST == 2 ? L.dist : L.t_min;
                 if (NEST == 2 && enter_it && (flags & OBJ_XF) && (flags & OBJ_BOUNDS)) {
                     double e;
-                    enter_it = box_enter_svc(rec + 16, rec + 19, sl, e) && (bound >= e);
+                    enter_it = box_enter_svc(rec + 16, rec + 19, RTX_SL, e) && (bound >= e);
                 }
                 V3 ro = L.o, rd = L.d;
                 if (enter_it && (flags & OBJ_XF)) {
@@ -2081,7 +2081,7 @@ RTX_DEV unsigned long long traverse_steps(const Scene& S, const Wave& wv, Lane& 
                     bound = __longlong_as_double(__double_as_longlong(bound) + 1ll);
                 }
                 if (enter_it) {
-                    const Slab os = (flags & OBJ_XF) ? make_slab(ro, rd) : sl;
+                    const Slab os = (flags & OBJ_XF) ? make_slab(ro, rd) : RTX_SL;
                     double e;
                     enter_it = box_enter_svc(rec + 22, rec + 25, os, e) && (bound >= e);
                     if (enter_it) {
@@ -2092,7 +2092,6 @@ RTX_DEV unsigned long long traverse_steps(const Scene& S, const Wave& wv, Lane& 
                         L.is_shadow &= 1;
                         if (NEST == 1) { L.age = 0; if (shadow) { L.is_shadow = 3; L.orig_t_min = bound; } }
                         L.ro = ro; L.rd = rd; L.ix = os.ix; L.iy = os.iy; L.iz = os.iz; L.par = os.par;
-                        sl = os;
                         L.cur_ref = root_ref; L.cur_cnt = root_count; L.btri = -1;
                     }
                 }
@@ -2108,8 +2107,8 @@ RTX_DEV unsigned long long traverse_steps(const Scene& S, const Wave& wv, Lane& 
                     c[k].cnt = k & 1 ? __double2hiint(nd[26 + (k >> 1)]) : __double2loint(nd[26 + (k >> 1)]);
                     double e;
                     bool hit;
-                    if (any_par) hit = box_enter(nd + 6 * k, nd + 6 * k + 3, sl, e);
-                    else hit = box_enter_nopar(nd + 6 * k, nd + 6 * k + 3, sl, e);
+                    if (any_par) hit = box_enter(nd + 6 * k, nd + 6 * k + 3, RTX_SL, e);
+                    else hit = box_enter_nopar(nd + 6 * k, nd + 6 * k + 3, RTX_SL, e);
                     c[k].e = e;
                     const bool pass = hit & ((NEST ? t_cmp : L.t_min) >= e);
                     c[k].ok = pass & (c[k].cnt >= 0 || (NEST && nl && c[k].cnt == -2));
@@ -2204,7 +2203,6 @@ RTX_DEV unsigned long long traverse_steps(const Scene& S, const Wave& wv, Lane& 
             L.ro = L.o; L.rd = L.d;
             const Slab ws = make_slab(L.o, L.d);
             L.ix = ws.ix; L.iy = ws.iy; L.iz = ws.iz; L.par = ws.par;
-            sl = ws;
             L.is_shadow &= 1;
             L.cur_ref = 0; L.cur_cnt = -1;
             need_pop = L.sp <= 0;            // (with entries left the pop is next step's; without, the walk is over)
