@@ -733,6 +733,23 @@ def measure_static(R: Rank, args, name, mode, steps, warmup, with_cpu, pipelined
                     "what": "rtx_scene_set_wide_blas: three levels of the reference's BVH per 256-byte record, float boxes rounded "
                             "outward, one stack entry per record, every job's result checked against the reference's exact leaf box",
                     "record_bytes": ds.record_bytes(), "record_bytes_default": timed_ds.record_bytes()}
+            # The non-parity mode (rtx_scene_set_consistent: bounds carried into object space, any-hit shadow
+            # rays) over both record kinds -- its own figures, never the headline's.
+            if not args.consistent:
+                ds.set_consistent(True)
+                cw_first = ds.render(first_cam)[0].copy()
+                el_cw, _, _ = timed(R, step, steps, 1)
+                ds.set_consistent(False)
+                wide_ds, ds = ds, timed_ds
+                ds.set_consistent(True)
+                c_first = ds.render(first_cam)[0].copy()
+                el_c, _, _ = timed(R, step, steps, 1)
+                ds.set_consistent(False)
+                ds = wide_ds
+                wide["consistent_mode"] = {"ms_per_frame": el_c / steps * 1e3, "ms_per_frame_wide_blas": el_cw / steps * 1e3,
+                                           "wide_blas_identical_to_four_wide": bool(np.array_equal(c_first, cw_first)),
+                                           "note": "not the reference's picture where instances are scaled or buried; checked against its own "
+                                                   "CPU checker in the tests"}
         ds.close()
         ds = timed_ds
     # mode tiles: the assembled frame against the same frame rendered whole on rank 0

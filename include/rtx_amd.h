@@ -183,7 +183,8 @@ typedef struct rtx_stats {
     /* Of shadow_rays: those that no object of the scene could hold up -- every mesh and instance turns
      * them down at its first box test -- and that the shading kernel therefore settled on the spot
      * (isInShadow, utils.cpp:1066-1084, answers "no") instead of queueing them for the trace kernel.
-     * Default mode, scenes without planes, spheres and free triangles; 0 otherwise. */
+     * Default and consistent mode, scenes without planes, spheres and free triangles; 0 otherwise
+     * (and with work counters on, when every query is carried out). */
     uint64_t shadow_rays_settled_early;
 } rtx_stats;
 

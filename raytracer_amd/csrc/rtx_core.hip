@@ -1294,11 +1294,12 @@ int job_start_attempt(rtx_frame* fr) {
     // ... and, in scenes that are not dominated by instance replay, of the long-running jobs of
     // every generation's drained waves (a kernel variant of its own; see k_trace)
     launch.chunk_max = replay_heavy ? RTX_CHUNK_INSTANCED : RTX_CHUNK;
-    // shadow rays that no object can hold up are settled by the shading kernel (shadow_ray_is_free): default mode
-    // only (with counters on every query is carried out; the consistent mode's bound is the light's distance)
+    // shadow rays that no object can hold up are settled by the shading kernel (shadow_ray_is_free), in the default
+    // and the consistent mode (whose bound, the light's distance, turns down nothing that no bound lets in); with
+    // counters on every query is carried out
     {
         const int n_lin = J.dev.n_meshes + (J.dev.n_insts <= RTX_LINEAR_INSTS ? J.dev.n_insts : 0);
-        launch.early_shadow = (!J.counters_on && !J.consistent && !(J.debug & RTX_DEBUG_NO_EARLY_SHADOW) &&
+        launch.early_shadow = (!J.counters_on && !(J.debug & RTX_DEBUG_NO_EARLY_SHADOW) &&
                                J.dev.n_planes == 0 && J.dev.n_spheres == 0 && J.dev.n_ftris == 0 && n_lin <= 16 &&
                                J.dev.n_lights <= 32) ? 1u : 0u;
     }

@@ -846,9 +846,10 @@ RTX_DEV int job_next(const Scene& S, const ObjCache& oc, Lane& L, const RecOut& 
 // and instance turns it down at the FIRST test job_next would make for it -- the world box of a
 // transformed object (utils.cpp:446-466, 760-766), the root box of an untransformed one (bvh.cpp:132), the
 // TLAS root for instances beyond the linear few -- with the same arithmetic on the same origin and
-// direction the queue would carry, and the bound a fresh shadow ray has in the default mode (DBL_MAX:
-// every entry distance is below it).  Such a ray runs no job, accepts no hit and ends by adding its
-// unshadowed contribution (service_lane, "ray complete"), which the caller does at once instead.
+// direction the queue would carry; the bound plays no part (a box missed for every bound is missed
+// for the light's distance, the consistent mode's bound, as for DBL_MAX, the default mode's).  Such a
+// ray runs no job, accepts no hit and ends by adding its unshadowed contribution (service_lane, "ray
+// complete"), which the caller does at once instead.
 // Only for scenes without planes, spheres and free triangles (the host decides: Launch::early_shadow);
 // anything not plainly turned down -- an object without a world box, a box test that passes -- leaves the
 // ray to the trace kernel.

@@ -261,7 +261,7 @@ def test_shadow_rays_settled_early_change_nothing(unit_scenes, name):
     """isInShadow (utils.cpp:1066-1084) for a ray that every mesh and instance turns down at its first
     box test: the default path answers it where the ray would be emitted.  Same bytes, same hit records
     and the same ray counts as with every shadow ray queued and traced (RTX_DEBUG_NO_EARLY_SHADOW), and
-    the oracle's ray count; in the consistent mode and with counters on nothing is settled early."""
+    the oracle's ray count; the consistent mode likewise; with counters on nothing is settled early."""
     from raytracer_amd import _abi
     if name not in unit_scenes:
         pytest.skip("no such unit scene")
@@ -285,7 +285,12 @@ def test_shadow_rays_settled_early_change_nothing(unit_scenes, name):
     ds.set_counters(True)
     assert ds.render(cam)[2]["shadow_rays_settled_early"] == 0
     ds.set_counters(False)
+    # the consistent mode settles them too: same bytes as with every shadow ray traced
     ds.set_consistent(True)
-    assert ds.render(cam)[2]["shadow_rays_settled_early"] == 0
+    c_rgb, c_hits, c_st = ds.render(cam, want_hits=True)
+    ds.set_debug(_abi.DEBUG_NO_EARLY_SHADOW)
+    cq_rgb, cq_hits, cq_st = ds.render(cam, want_hits=True)
+    assert cq_st["shadow_rays_settled_early"] == 0 and c_st["rays"] == cq_st["rays"]
+    assert np.array_equal(c_rgb, cq_rgb) and np.array_equal(c_hits, cq_hits), name
     ds.close(); hs.close()
 
