@@ -1,6 +1,7 @@
 """Dev helper (GPU box): one frame rendered as K interleaved tile subsets on K frame contexts at once
-(tile t in subset t mod K), against the frame rendered whole.
-Usage: python tools/subframes.py <workload> [tile_w tile_h]"""
+(tile t in subset t mod K), against the frame rendered whole.  The tile buffers are pageable: their host-side
+copies overlap the other subsets' kernels, which flatters the subsets by 3-4 % against the whole frame's one copy.
+Usage: python tools/subframes.py <workload> [tile_w tile_h [half]]   (half: every subset on a grid of one wave per SIMD)"""
 import ctypes as C
 import os
 import sys
@@ -25,6 +26,10 @@ t0 = time.perf_counter()
 for _ in range(10):
     ds.render(cam)
 print(f"{name}: whole frame {(time.perf_counter() - t0) / 10 * 1e3:.3f} ms", flush=True)
+if len(sys.argv) > 4 and sys.argv[4] == "half":
+    from raytracer_amd import _abi
+    ds.set_debug(_abi.DEBUG_HALF_GRID)
+    print("subsets on half grids", flush=True)
 for k in (2, 3, 4, 6, 8):
     frames = [ds.frame() for _ in range(k)]
     bufs = [np.empty(lib.rtx_render_output_bytes(C.byref(cam), tw, th, i, k), dtype=np.uint8) for i in range(k)]
